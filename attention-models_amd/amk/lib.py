@@ -1,0 +1,71 @@
+"""ctypes binding of libamk.so (the C ABI declared in include/amk.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950) and lives next to
+this file.  There is no fallback: if the shared object is missing, or a kernel reports an
+error, this module raises.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libamk.so")
+HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "amk.h"))
+
+AMK_OK = 0
+
+_c = ctypes
+_P = _c.c_void_p
+_I = _c.c_int
+_L = _c.c_int64
+_F = _c.c_float
+
+# name -> (restype, argtypes); mirrors include/amk.h one to one (tests/test_abi.py checks it).
+SIGNATURES = {
+    "amk_version": (_I, []),
+    "amk_arch": (_c.c_char_p, []),
+    "amk_last_error": (_c.c_char_p, []),
+    "amk_attn_fwd": (_I, [_P] * 7 + [_I] * 5 + [_L] * 12 + [_F, _P]),
+    "amk_attn_bwd": (_I, [_P] * 12 + [_I] * 5 + [_L] * 24 + [_F, _P]),
+    "amk_vq_num_partials": (_L, [_L]),
+    "amk_vq_lookup_fwd": (_I, [_P, _P, _L, _I, _I, _I] + [_P] * 9 + [_P]),
+    "amk_vq_lookup_bwd": (_I, [_P] * 7 + [_F, _L, _I, _I, _P, _P, _P]),
+    "amk_vq_gather": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+}
+
+_lib = None
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Function names declared in include/amk.h (used by the ABI test)."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(amk_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load libamk.so once and type every entry point."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). amk has no CPU or eager fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    arch = lib.amk_arch().decode()
+    if arch != "gfx950":
+        raise RuntimeError(f"libamk.so was built for {arch}, expected gfx950")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != AMK_OK:
+        msg = load().amk_last_error().decode()
+        raise RuntimeError(f"{what} failed with code {rc}: {msg}")

@@ -1,0 +1,6 @@
+"""Same export list as the reference's ``models`` package (models/__init__.py:1-14) for the
+classes on the hot path and their scaffolding."""
+from .attention import SoftmaxAttention
+from .vitvqgan import Codebook, ViTVQGAN
+
+__all__ = ["SoftmaxAttention", "Codebook", "ViTVQGAN"]

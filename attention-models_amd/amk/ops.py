@@ -1,0 +1,276 @@
+"""torch.autograd wrappers over the libamk.so C ABI.
+
+torch is plumbing here: it owns device memory, streams and the autograd graph; every FLOP of
+the hot path runs in the HIP kernels of ``csrc/``.  Inputs must be fp32 HIP tensors -- there
+is deliberately no CPU / eager path ("no fallback").
+"""
+import ctypes
+
+import torch
+
+from . import lib as _lib
+
+_NULL = ctypes.c_void_p(0)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else _NULL
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_device(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "amk ops run only on MI355X (HIP) tensors; got a CPU tensor. There is no CPU fallback."
+            )
+        if t.is_floating_point() and t.dtype != torch.float32:
+            raise RuntimeError(f"amk kernels compute in fp32; got {t.dtype}")
+
+
+# ---------------------------------------------------------------------------- attention
+def _strides4(t):
+    """(sb, st, sh) element strides of a (B, H, T, D) view whose last axis is contiguous."""
+    return (t.stride(0), t.stride(2), t.stride(1))
+
+
+def _kernel_view_ok(t):
+    return (
+        t.stride(3) == 1
+        and t.data_ptr() % 16 == 0
+        and all(s % 4 == 0 for s in (t.stride(0), t.stride(1), t.stride(2)))
+    )
+
+
+def _as_kernel_view(t):
+    """Return a (B,H,T,D) view the kernels can address; copy only if the layout forces it."""
+    if _kernel_view_ok(t):
+        return t
+    B, H, T, D = t.shape
+    return t.permute(0, 2, 1, 3).contiguous().permute(0, 2, 1, 3)  # (B,T,H,D) storage
+
+
+def _new_bthd(B, H, T, D, like):
+    """(B,H,T,D) view over fresh (B,T,H*D) storage: the layout the W_o projection consumes."""
+    return torch.empty((B, T, H, D), device=like.device, dtype=torch.float32).permute(0, 2, 1, 3)
+
+
+def _mask_u8(mask, shape, what):
+    if mask is None:
+        return None
+    m = mask
+    while m.dim() > len(shape) and m.shape[0] == 1:
+        m = m[0]
+    if m.dim() != len(shape):
+        raise RuntimeError(f"{what} must have {len(shape)} dims (got shape {tuple(mask.shape)})")
+    m = m.expand(*shape)
+    return m.to(torch.uint8).contiguous()
+
+
+def _attn_forward(q, k, v, key_mask, causal_mask, scale):
+    B, H, I, D = q.shape
+    J = k.shape[2]
+    _require_device(q, k, v, key_mask, causal_mask)
+    if k.shape != (B, H, J, D) or v.shape != (B, H, J, D):
+        raise RuntimeError(f"attention shapes disagree: q {tuple(q.shape)} k {tuple(k.shape)} v {tuple(v.shape)}")
+    q, k, v = _as_kernel_view(q), _as_kernel_view(k), _as_kernel_view(v)
+    o = _new_bthd(B, H, I, D, q)
+    stats = torch.empty((B, H, I, 2), device=q.device, dtype=torch.float32)
+    L = _lib.load()
+    rc = L.amk_attn_fwd(
+        _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(key_mask), _ptr(causal_mask),
+        B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
+        float(scale), _stream(),
+    )
+    _lib.check(rc, "amk_attn_fwd")
+    return q, k, v, o, stats
+
+
+def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, scale):
+    B, H, I, D = q.shape
+    J = k.shape[2]
+    d_o = _as_kernel_view(d_o)
+    delta = torch.empty((B, H, I), device=q.device, dtype=torch.float32)
+    L = _lib.load()
+    rc = L.amk_attn_bwd(
+        _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(d_o),
+        _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), _ptr(key_mask), _ptr(causal_mask),
+        B, H, I, J, D,
+        *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o), *_strides4(d_o),
+        *_strides4(dq), *_strides4(dk), *_strides4(dv),
+        float(scale), _stream(),
+    )
+    _lib.check(rc, "amk_attn_bwd")
+
+
+class _AttnCore(torch.autograd.Function):
+    """o = softmax(fill(q*scale @ k^T)) @ v on (B,H,T,D) views."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, key_mask, causal_mask, scale):
+        q, k, v, o, stats = _attn_forward(q, k, v, key_mask, causal_mask, scale)
+        ctx.save_for_backward(q, k, v, o, stats, key_mask, causal_mask)
+        ctx.scale = scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, stats, key_mask, causal_mask = ctx.saved_tensors
+        B, H, I, D = q.shape
+        J = k.shape[2]
+        dq = _new_bthd(B, H, I, D, q)
+        dk = _new_bthd(B, H, J, D, q)
+        dv = _new_bthd(B, H, J, D, q)
+        _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, ctx.scale)
+        return dq, dk, dv, None, None, None
+
+
+class _AttnFusedKV(torch.autograd.Function):
+    """Same core fed by the projection outputs in place: q (B,I,h*d), kv (B,J,2*h*d) with the
+    reference's '(kv h d)' column order (models/softmax_attention.py:39); returns (B,I,h*d).
+    The backward writes dk and dv straight into one (B,J,2*h*d) buffer."""
+
+    @staticmethod
+    def forward(ctx, q2, kv2, key_mask, causal_mask, H, D, scale):
+        B, I, _ = q2.shape
+        J = kv2.shape[1]
+        q2 = q2.contiguous()
+        kv2 = kv2.contiguous()
+        q = q2.view(B, I, H, D).permute(0, 2, 1, 3)
+        kv = kv2.view(B, J, 2, H, D)
+        k = kv[:, :, 0].permute(0, 2, 1, 3)
+        v = kv[:, :, 1].permute(0, 2, 1, 3)
+        q, k, v, o, stats = _attn_forward(q, k, v, key_mask, causal_mask, scale)
+        ctx.save_for_backward(q, k, v, o, stats, key_mask, causal_mask)
+        ctx.scale = scale
+        return o.permute(0, 2, 1, 3).reshape(B, I, H * D)
+
+    @staticmethod
+    def backward(ctx, d_o2):
+        q, k, v, o, stats, key_mask, causal_mask = ctx.saved_tensors
+        B, H, I, D = q.shape
+        J = k.shape[2]
+        d_o = d_o2.contiguous().view(B, I, H, D).permute(0, 2, 1, 3)
+        dq2 = torch.empty((B, I, H * D), device=q.device, dtype=torch.float32)
+        dkv2 = torch.empty((B, J, 2 * H * D), device=q.device, dtype=torch.float32)
+        dq = dq2.view(B, I, H, D).permute(0, 2, 1, 3)
+        dkv = dkv2.view(B, J, 2, H, D)
+        dk = dkv[:, :, 0].permute(0, 2, 1, 3)
+        dv = dkv[:, :, 1].permute(0, 2, 1, 3)
+        _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, ctx.scale)
+        return dq2, dkv2, None, None, None, None, None
+
+
+def attention(q, k, v, scale, key_mask=None, causal_mask=None):
+    """Fused attention core on (B,H,T,D) tensors (any strides with a contiguous last axis).
+
+    key_mask: bool (B,J), True = keep (reference ``context_mask``); causal_mask: bool (I,J),
+    True = masked (reference ``causal_mask``); both filled with -1e9 as masked_fill does.
+    """
+    B, H, I, D = q.shape
+    J = k.shape[2]
+    km = _mask_u8(key_mask, (B, J), "context_mask")
+    cm = _mask_u8(causal_mask, (I, J), "causal_mask")
+    return _AttnCore.apply(q, k, v, km, cm, scale)
+
+
+def attention_fused_kv(q2, kv2, num_heads, dim_head, scale, key_mask=None, causal_mask=None):
+    """q2 (B,I,h*d), kv2 (B,J,2*h*d) -> (B,I,h*d); see _AttnFusedKV."""
+    B, I, _ = q2.shape
+    J = kv2.shape[1]
+    km = _mask_u8(key_mask, (B, J), "context_mask")
+    cm = _mask_u8(causal_mask, (I, J), "causal_mask")
+    return _AttnFusedKV.apply(q2, kv2, km, cm, num_heads, dim_head, scale)
+
+
+# ---------------------------------------------------------------------------- VQ lookup
+def vq_nsplit(N, K):
+    """Codebook slices per row block: enough workgroups (>= 2 per CU) without slices < 256 codes."""
+    row_blocks = (N + 127) // 128
+    nsplit = 1
+    while row_blocks * nsplit < 512 and K % (64 * nsplit) == 0 and K // (2 * nsplit) >= 256:
+        nsplit *= 2
+    return nsplit
+
+
+class _VQLookup(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, codebook, beta):
+        _require_device(z, codebook)
+        C = z.shape[-1]
+        K = codebook.shape[0]
+        zf = z.contiguous().view(-1, C)
+        cb = codebook.contiguous()
+        N = zf.shape[0]
+        dev = z.device
+        L = _lib.load()
+        nsplit = vq_nsplit(N, K)
+        f32 = dict(device=dev, dtype=torch.float32)
+        en = torch.empty((K, C), **f32)
+        ee = torch.empty((K,), **f32)
+        pmin = torch.empty((N, nsplit), **f32)
+        pidx = torch.empty((N, nsplit), device=dev, dtype=torch.int32)
+        idx = torch.empty((N,), device=dev, dtype=torch.int64)
+        out = torch.empty((N, C), **f32)
+        zq = torch.empty((N, C), **f32)
+        zn = torch.empty((N, C), **f32)
+        partial = torch.empty((L.amk_vq_num_partials(N),), **f32)
+        rc = L.amk_vq_lookup_fwd(
+            _ptr(zf), _ptr(cb), N, K, C, nsplit, _ptr(en), _ptr(ee), _ptr(pmin), _ptr(pidx),
+            _ptr(idx), _ptr(out), _ptr(zq), _ptr(zn), _ptr(partial), _stream(),
+        )
+        _lib.check(rc, "amk_vq_lookup_fwd")
+        mean_sq = partial.sum() / float(N * C)
+        # beta*mean((zq.detach()-z)^2) + mean((zq-z.detach())^2): the two means are one value
+        loss = beta * mean_sq + mean_sq
+        ctx.save_for_backward(zf, cb, zn, zq, idx)
+        ctx.beta = beta
+        ctx.z_shape = z.shape
+        idx_v = idx.view(z.shape[:-1])
+        ctx.mark_non_differentiable(idx_v)
+        return out.view(z.shape), idx_v, loss
+
+    @staticmethod
+    def backward(ctx, g_out, _g_idx, g_loss):
+        zf, cb, zn, zq, idx = ctx.saved_tensors
+        N, C = zf.shape
+        K = cb.shape[0]
+        if g_out is None:
+            g_out = torch.zeros_like(zf)
+        if g_loss is None:
+            g_loss = torch.zeros((), device=zf.device, dtype=torch.float32)
+        g_out = g_out.contiguous().view(N, C)
+        g_loss = g_loss.contiguous().to(torch.float32)
+        dz = torch.empty_like(zf)
+        dcb = torch.empty_like(cb)
+        L = _lib.load()
+        rc = L.amk_vq_lookup_bwd(
+            _ptr(zf), _ptr(cb), _ptr(zn), _ptr(zq), _ptr(idx), _ptr(g_out), _ptr(g_loss),
+            float(ctx.beta), N, K, C, _ptr(dz), _ptr(dcb), _stream(),
+        )
+        _lib.check(rc, "amk_vq_lookup_bwd")
+        return dz.view(ctx.z_shape), dcb, None
+
+
+def vq_lookup(z, codebook, beta):
+    """Codebook.forward of the reference: returns (z_q straight-through, int64 indices, loss)."""
+    return _VQLookup.apply(z, codebook, beta)
+
+
+def vq_gather(indices, codebook):
+    """Codebook.indices_to_embeddings: l2norm(E[indices]).  Differentiable w.r.t. nothing
+    (the reference only uses it for decoding under no_grad / frozen VQ)."""
+    _require_device(indices, codebook)
+    K, C = codebook.shape
+    flat = indices.contiguous().view(-1).to(torch.int64)
+    N = flat.shape[0]
+    out = torch.empty((N, C), device=codebook.device, dtype=torch.float32)
+    L = _lib.load()
+    rc = L.amk_vq_gather(_ptr(flat), _ptr(codebook.detach().contiguous()), N, K, C, _ptr(out), _stream())
+    _lib.check(rc, "amk_vq_gather")
+    return out.view(*indices.shape, C)

@@ -1,0 +1,247 @@
+// Fused softmax-attention forward for gfx950 (exact-f32 MFMA, flash-style online softmax).
+//
+// Replaces models/softmax_attention.py:62-76 of the reference: einsum QK^T -> two
+// masked_fill(-1e9) -> softmax -> einsum PV, which materialise the (B,h,I,J) scores
+// several times in HBM.  Here a workgroup (4 waves, one per SIMD) owns 128 query rows
+// of one (batch, head); each wave owns 32 of them with the QUERY ON THE LANE:
+//
+//   S^T tile (32 keys x 32 queries) = K_tile (A operand, rows from LDS, ds_read_b128)
+//                                     x Q^T (B operand, 32 registers, loaded once)
+//   -> lane (query = l&31, half = l>>5) holds 16 keys of its query per 32-key tile, so
+//      the row max / row sum are in-register plus ONE cross-half exchange per 64 keys;
+//   O^T tile (32 dims x 32 queries) += V_tile^T (A operand, ds_read_b32 column reads)
+//                                      x P^T (B operand = the S^T accumulator registers
+//                                      as they stand: no LDS round trip, no shuffles)
+//   -> O stays query-on-lane too, so the online-softmax rescale is a per-lane scalar.
+//
+// K/V tiles of 64 keys are staged global -> registers -> LDS (loads for tile t+1 are
+// issued before the MFMAs of tile t and written after them).
+#include "attn_common.h"
+
+namespace amk_attn {
+
+template <bool CAUSAL>
+__global__ __launch_bounds__(WG, 2) void attn_fwd_kernel(FwdParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * TILE * LDS_STRIDE + TILE];
+  float* Ks = smem;
+  float* Vs = smem + TILE * LDS_STRIDE;
+  float* Kfill = smem + 2 * TILE * LDS_STRIDE;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, hf = lane >> 5;
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = wg % p.nblk;
+  const int bh = wg / p.nblk;
+  const int h = bh % p.H, b = bh / p.H;
+
+  const int qi = qb * BLK + wave * 32 + ln;  // this lane's query row
+  const bool qvalid = qi < p.I;
+
+  // Q^T operand: lane (query, half) holds (q * scale)[query][32*half + s], s = 0..31.
+  float qreg[32];
+  {
+    const float* qp = p.q + (int64_t)b * p.qs.sb + (int64_t)qi * p.qs.st + (int64_t)h * p.qs.sh + 32 * hf;
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      float4 t = qvalid ? ld4(qp + 4 * s4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qreg[4 * s4 + 0] = t.x * p.scale;
+      qreg[4 * s4 + 1] = t.y * p.scale;
+      qreg[4 * s4 + 2] = t.z * p.scale;
+      qreg[4 * s4 + 3] = t.w * p.scale;
+    }
+  }
+
+  const float* kbase = p.k + (int64_t)b * p.ks.sb + (int64_t)h * p.ks.sh;
+  const float* vbase = p.v + (int64_t)b * p.vs.sb + (int64_t)h * p.vs.sh;
+  const uint8_t* kmask = p.key_mask ? p.key_mask + (int64_t)b * p.J : nullptr;
+  const uint8_t* cmrow = CAUSAL ? p.causal_mask + (int64_t)qi * p.J : nullptr;
+
+  // staging registers: thread -> (row = tid/16 + 16*pass, 4 floats at column 4*(tid%16))
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  float4 kst[4], vst[4];
+  float fillst = 0.f;
+
+  auto prefetch = [&](int j0) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int j = j0 + srow + 16 * ps;
+      if (j < p.J) {
+        kst[ps] = ld4(kbase + (int64_t)j * p.ks.st + scol);
+        vst[ps] = ld4(vbase + (int64_t)j * p.vs.st + scol);
+      } else {
+        kst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+        vst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    if (tid < TILE) {
+      const int j = j0 + tid;
+      float f = 0.f;
+      if (j >= p.J) f = -INFINITY;                       // beyond the sequence: weight 0
+      else if (kmask && kmask[j] == 0) f = AMK_FILL_MASKED;  // masked_fill(~context_mask, -1e9)
+      fillst = f;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int r = srow + 16 * ps;
+      st4(&Ks[r * LDS_STRIDE + scol], kst[ps]);
+      st4(&Vs[r * LDS_STRIDE + scol], vst[ps]);
+    }
+    if (tid < TILE) Kfill[tid] = fillst;
+  };
+
+  f32x16 o0 = zero16(), o1 = zero16();
+  float m_run = -INFINITY, l_run = 0.f;
+
+  const int ntile = (p.J + TILE - 1) / TILE;
+  prefetch(0);
+  for (int t = 0; t < ntile; ++t) {
+    const int j0 = t * TILE;
+    __syncthreads();  // every wave is done reading the previous tile
+    commit();
+    __syncthreads();
+    if (t + 1 < ntile) prefetch(j0 + TILE);
+
+    // causal bytes of this lane's query row for the 2 x 16 keys it will own in this tile
+    unsigned cbits0 = 0, cbits1 = 0;
+    if (CAUSAL) {
+      if (qvalid) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ja = j0 + acc_row(r, hf), jb = ja + 32;
+          if (ja < p.J && cmrow[ja]) cbits0 |= 1u << r;
+          if (jb < p.J && cmrow[jb]) cbits1 |= 1u << r;
+        }
+      }
+    }
+
+    // ---- S^T = K Q^T for the two 32-key halves of the tile (2 x 32 MFMAs) ----
+    f32x16 s0 = zero16(), s1 = zero16();
+    {
+      const float* k0 = &Ks[ln * LDS_STRIDE + 32 * hf];
+      const float* k1 = &Ks[(32 + ln) * LDS_STRIDE + 32 * hf];
+#pragma unroll
+      for (int s4 = 0; s4 < 8; ++s4) {
+        const float4 a0 = ld4(k0 + 4 * s4);
+        const float4 a1 = ld4(k1 + 4 * s4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          s0 = mfma32(f4(a0, e), qreg[4 * s4 + e], s0);
+          s1 = mfma32(f4(a1, e), qreg[4 * s4 + e], s1);
+        }
+      }
+    }
+
+    // ---- fills, log2 scaling, online softmax (lane-local + one cross-half exchange) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 f0 = ld4(&Kfill[8 * g + 4 * hf]);
+      const float4 f1 = ld4(&Kfill[32 + 8 * g + 4 * hf]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        float t0 = s0[r] * AMK_LOG2E, t1 = s1[r] * AMK_LOG2E;
+        const float fa = f4(f0, e), fb = f4(f1, e);
+        t0 = (fa == 0.f) ? t0 : fa;
+        t1 = (fb == 0.f) ? t1 : fb;
+        if (CAUSAL) {
+          t0 = ((cbits0 >> r) & 1u) ? AMK_FILL_MASKED : t0;
+          t1 = ((cbits1 >> r) & 1u) ? AMK_FILL_MASKED : t1;
+        }
+        s0[r] = t0;
+        s1[r] = t1;
+        mx = fmaxf(mx, fmaxf(t0, t1));
+      }
+    }
+    mx = wave_xor32_max(mx);
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = __builtin_amdgcn_exp2f(s0[r] - m_new);
+      const float p1 = __builtin_amdgcn_exp2f(s1[r] - m_new);
+      s0[r] = p0;
+      s1[r] = p1;
+      lsum += p0 + p1;
+    }
+    l_run = l_run * alpha + lsum;
+    m_run = m_new;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      o0[r] *= alpha;
+      o1[r] *= alpha;
+    }
+
+    // ---- O^T += V^T P^T (2 x 32 MFMAs); P^T is the S^T accumulator as it stands ----
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* v0 = &Vs[acc_row(r, hf) * LDS_STRIDE + ln];
+      const float* v1 = &Vs[(32 + acc_row(r, hf)) * LDS_STRIDE + ln];
+      o0 = mfma32(v0[0], s0[r], o0);
+      o1 = mfma32(v0[32], s0[r], o1);
+      o0 = mfma32(v1[0], s1[r], o0);
+      o1 = mfma32(v1[32], s1[r], o1);
+    }
+  }
+
+  // ---- epilogue: normalise, store O rows and the softmax statistics ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (qvalid) {
+    float* op = p.o + (int64_t)b * p.os.sb + (int64_t)qi * p.os.st + (int64_t)h * p.os.sh + 4 * hf;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      st4(op + 8 * g, make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv));
+      st4(op + 32 + 8 * g, make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv));
+    }
+    if (hf == 0) {
+      float* sp = p.stats + (((int64_t)b * p.H + h) * p.I + qi) * 2;
+      sp[0] = m_run;
+      sp[1] = l_tot;
+    }
+  }
+}
+
+}  // namespace amk_attn
+
+using namespace amk_attn;
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool strides_ok(const Strides& s) { return (s.sb % 4 == 0) && (s.st % 4 == 0) && (s.sh % 4 == 0); }
+
+extern "C" int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float* stats,
+                            const uint8_t* key_mask, const uint8_t* causal_mask,
+                            int B, int H, int I, int J, int Dh,
+                            int64_t q_sb, int64_t q_st, int64_t q_sh,
+                            int64_t k_sb, int64_t k_st, int64_t k_sh,
+                            int64_t v_sb, int64_t v_st, int64_t v_sh,
+                            int64_t o_sb, int64_t o_st, int64_t o_sh,
+                            float scale, void* stream) {
+  AMK_CHECK_ARG(q && k && v && o && stats, "amk_attn_fwd: null tensor pointer");
+  AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_fwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
+  AMK_CHECK_SUPPORTED(Dh == D, "amk_attn_fwd: head dim %d not supported (built for %d)", Dh, D);
+  FwdParams p;
+  p.q = q; p.k = k; p.v = v; p.o = o; p.stats = stats;
+  p.key_mask = key_mask; p.causal_mask = causal_mask;
+  p.B = B; p.H = H; p.I = I; p.J = J;
+  p.qs = {q_sb, q_st, q_sh}; p.ks = {k_sb, k_st, k_sh}; p.vs = {v_sb, v_st, v_sh}; p.os = {o_sb, o_st, o_sh};
+  p.scale = scale;
+  p.nblk = (I + BLK - 1) / BLK;
+  AMK_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && strides_ok(p.qs) &&
+                    strides_ok(p.ks) && strides_ok(p.vs) && strides_ok(p.os),
+                "amk_attn_fwd: pointers must be 16-byte aligned and strides multiples of 4 elements");
+  const int64_t nwg = (int64_t)B * H * p.nblk;
+  AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_fwd: grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (causal_mask)
+    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)nwg), dim3(WG), 0, st, p);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)nwg), dim3(WG), 0, st, p);
+  AMK_CHECK_LAUNCH("amk_attn_fwd");
+  return AMK_OK;
+}

@@ -1,0 +1,363 @@
+// ViTVQGAN codebook nearest-neighbour lookup for gfx950 (exact-f32 MFMA + in-register argmin).
+//
+// Replaces Codebook.forward of the reference (models/vitvqgan.py:151-171), which builds the
+// (N, K) distance matrix in HBM (33.5 MB per image at K = 8192) and re-reads it for the
+// adds and the argmin.  Here the matrix never leaves the register file:
+//
+//   vq_prep_codebook : en = l2norm(E), ee[k] = sum en[k]^2                     (K rows, tiny)
+//   vq_argmin        : Z-ROW ON THE LANE.  A workgroup owns 128 rows (32 per wave) and a
+//        contiguous slice of the codebook.  Per 32-code tile:
+//          dot^T (32 codes x 32 rows) = en_tile (A operand, LDS rows, ds_read_b128)
+//                                       x zn^T  (B operand, C/2 registers, loaded once)
+//          dist = (zz + ee[code]) - 2*dot   -- the reference's three-term expression, same
+//                                              association, one FMA for the exact "2*dot"
+//          running (min, argmin) per lane with strict '<' over ascending codes = torch.argmin's
+//          first-minimum rule; the two half-waves of a row are merged at the end.
+//   vq_finalize      : merges the per-slice (min, idx) partials (lowest index wins ties), gathers
+//        E[idx], re-normalises, forms the straight-through output and the squared-error partials.
+//   vq_bwd           : straight-through + commitment gradient to z through the l2-norm Jacobian;
+//        codebook rows receive 2(zq - zn)/(N*C) through their own Jacobian by f32 atomics
+//        (one 128-B segment per row per wave-instruction: the full-rate shape).
+#include "amk_common.h"
+
+namespace amk_vq {
+
+constexpr int ROWS_WG = 128;   // z rows per workgroup in vq_argmin (4 waves x 32)
+constexpr int CODES_LDS = 128; // codes staged per LDS tile (4 MFMA tiles of 32)
+constexpr int FIN_ROWS = 16;   // z rows per workgroup in vq_finalize
+constexpr float EPS = 1e-12f;  // F.normalize default eps
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float f4(const float4& v, int e) {
+  return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
+}
+
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void vq_prep_codebook_kernel(const float* __restrict__ E, int K,
+                                                               float* __restrict__ en, float* __restrict__ ee) {
+  // C/4 lanes per code row, one float4 each.
+  constexpr int LPR = C / 4;
+  const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  const int c = (threadIdx.x % LPR) * 4;
+  float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < K) x = ld4(E + (int64_t)row * C + c);
+  float ss = x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
+#pragma unroll
+  for (int o = LPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float denom = fmaxf(sqrtf(ss), EPS);
+  const float4 y = make_float4(x.x / denom, x.y / denom, x.z / denom, x.w / denom);
+  float s2 = y.x * y.x + y.y * y.y + y.z * y.z + y.w * y.w;
+#pragma unroll
+  for (int o = LPR / 2; o >= 1; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+  if (row < K) {
+    st4(en + (int64_t)row * C + c, y);
+    if (c == 0) ee[row] = s2;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restrict__ z, const float* __restrict__ en,
+                                                          const float* __restrict__ ee, int64_t N, int K, int nsplit,
+                                                          float* __restrict__ zn_out, float* __restrict__ pmin,
+                                                          int32_t* __restrict__ pidx) {
+  constexpr int HC = C / 2;       // k-extent owned by one half-wave
+  constexpr int LS = C + 4;       // LDS row stride: conflict-free ds_read_b128 row reads
+  __shared__ __attribute__((aligned(16))) float smem[CODES_LDS * LS + CODES_LDS];
+  float* Es = smem;
+  float* EEs = smem + CODES_LDS * LS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, hf = lane >> 5;
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int split = wg % nsplit;       // consecutive ids share the z rows, walk the slices
+  const int64_t rb = wg / nsplit;
+  const int64_t row = rb * ROWS_WG + wave * 32 + ln;
+  const bool rvalid = row < N;
+
+  // zn^T operand: lane (row, half) holds zn[row][HC*half + s]; l2norm needs the other half's sum.
+  float zreg[HC];
+  {
+    const float* zp = z + row * C + HC * hf;
+    float ss = 0.f;
+#pragma unroll
+    for (int s4 = 0; s4 < HC / 4; ++s4) {
+      const float4 t = rvalid ? ld4(zp + 4 * s4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      zreg[4 * s4 + 0] = t.x; zreg[4 * s4 + 1] = t.y; zreg[4 * s4 + 2] = t.z; zreg[4 * s4 + 3] = t.w;
+      ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
+    }
+    ss += __shfl_xor(ss, 32, 64);
+    const float denom = fmaxf(sqrtf(ss), EPS);
+#pragma unroll
+    for (int s = 0; s < HC; ++s) zreg[s] = zreg[s] / denom;
+  }
+  float zz = 0.f;
+#pragma unroll
+  for (int s = 0; s < HC; ++s) zz += zreg[s] * zreg[s];
+  zz += __shfl_xor(zz, 32, 64);
+  if (split == 0 && rvalid) {
+    float* op = zn_out + row * C + HC * hf;
+#pragma unroll
+    for (int s4 = 0; s4 < HC / 4; ++s4)
+      st4(op + 4 * s4, make_float4(zreg[4 * s4], zreg[4 * s4 + 1], zreg[4 * s4 + 2], zreg[4 * s4 + 3]));
+  }
+
+  const int kper = K / nsplit;          // codes in this slice (multiple of 32)
+  const int kbeg = split * kper;
+  const int ntile = (kper + CODES_LDS - 1) / CODES_LDS;
+
+  // staging: CODES_LDS*C floats per tile = (CODES_LDS*C/4) float4 over 256 threads
+  constexpr int NF4 = CODES_LDS * C / 4 / 256;
+  float4 est[NF4];
+  float eest = 0.f;
+  auto prefetch = [&](int t) {
+    const int c0 = kbeg + t * CODES_LDS;
+    const int lim = kbeg + kper;
+#pragma unroll
+    for (int ps = 0; ps < NF4; ++ps) {
+      const int f = tid + 256 * ps;
+      const int r = f / (C / 4), c4 = f % (C / 4);
+      est[ps] = (c0 + r < lim) ? ld4(en + (int64_t)(c0 + r) * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (tid < CODES_LDS) eest = (c0 + tid < lim) ? ee[c0 + tid] : INFINITY;  // +inf distance: never chosen
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < NF4; ++ps) {
+      const int f = tid + 256 * ps;
+      const int r = f / (C / 4), c4 = f % (C / 4);
+      st4(&Es[r * LS + 4 * c4], est[ps]);
+    }
+    if (tid < CODES_LDS) EEs[tid] = eest;
+  };
+
+  float best = INFINITY;
+  int bidx = kbeg;
+  prefetch(0);
+  for (int t = 0; t < ntile; ++t) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (t + 1 < ntile) prefetch(t + 1);
+    const int c0 = kbeg + t * CODES_LDS;
+    const int nsub = min(CODES_LDS, kper - t * CODES_LDS) / 32;
+    for (int u = 0; u < nsub; ++u) {
+      f32x16 acc;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      const float* er = &Es[(32 * u + ln) * LS + HC * hf];
+#pragma unroll
+      for (int s4 = 0; s4 < HC / 4; ++s4) {
+        const float4 a = ld4(er + 4 * s4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc = mfma32(f4(a, e), zreg[4 * s4 + e], acc);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 e4 = ld4(&EEs[32 * u + 8 * g + 4 * hf]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          // (sum z^2 + sum e^2) - 2*dot : same association as the reference expression
+          const float d = __builtin_fmaf(-2.f, acc[r], zz + f4(e4, e));
+          const int code = c0 + 32 * u + 8 * g + 4 * hf + e;
+          const bool lt = d < best;  // strict: the first minimum wins, codes ascend per lane
+          best = lt ? d : best;
+          bidx = lt ? code : bidx;
+        }
+      }
+    }
+  }
+  // merge the two half-waves of a row (they own interleaved codes): lowest index on ties
+  const float ob = __shfl_xor(best, 32, 64);
+  const int oi = __shfl_xor(bidx, 32, 64);
+  if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  if (rvalid && hf == 0) {
+    pmin[row * nsplit + split] = best;
+    pidx[row * nsplit + split] = bidx;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(FIN_ROWS * C / 4) void vq_finalize_kernel(
+    const float* __restrict__ E, const float* __restrict__ zn, const float* __restrict__ pmin,
+    const int32_t* __restrict__ pidx, int64_t N, int nsplit, int64_t* __restrict__ idx,
+    float* __restrict__ out, float* __restrict__ zq_out, float* __restrict__ sqerr_partial) {
+  constexpr int LPR = C / 4;
+  __shared__ float red[FIN_ROWS];
+  const int rl = threadIdx.x / LPR;
+  const int64_t row = (int64_t)blockIdx.x * FIN_ROWS + rl;
+  const int c = (threadIdx.x % LPR) * 4;
+  float err = 0.f;
+  if (row < N) {
+    float best = pmin[row * nsplit];
+    int bi = pidx[row * nsplit];
+    for (int s = 1; s < nsplit; ++s) {  // slices hold ascending code ranges: strict '<' keeps the first minimum
+      const float d = pmin[row * nsplit + s];
+      if (d < best) { best = d; bi = pidx[row * nsplit + s]; }
+    }
+    const float4 e = ld4(E + (int64_t)bi * C + c);
+    float ss = e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+#pragma unroll
+    for (int o = LPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float denom = fmaxf(sqrtf(ss), EPS);
+    const float4 q = make_float4(e.x / denom, e.y / denom, e.z / denom, e.w / denom);
+    const float4 zv = ld4(zn + row * C + c);
+    const float4 df = make_float4(q.x - zv.x, q.y - zv.y, q.z - zv.z, q.w - zv.w);
+    st4(zq_out + row * C + c, q);
+    st4(out + row * C + c, make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w));
+    if (c == 0) idx[row] = bi;
+    err = df.x * df.x + df.y * df.y + df.z * df.z + df.w * df.w;
+  }
+#pragma unroll
+  for (int o = LPR / 2; o >= 1; o >>= 1) err += __shfl_xor(err, o, 64);
+  if (threadIdx.x % LPR == 0) red[rl] = err;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < FIN_ROWS; ++i) s += red[i];
+    sqerr_partial[blockIdx.x] = s;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ z, const float* __restrict__ E,
+                                                     const float* __restrict__ zn, const float* __restrict__ zq,
+                                                     const int64_t* __restrict__ idx, const float* __restrict__ g_out,
+                                                     const float* __restrict__ g_loss, float beta, int64_t N,
+                                                     float* __restrict__ dz, float* __restrict__ dE) {
+  // one lane per element, C lanes per row: the codebook atomics of a wave then form
+  // 64/C whole 4*C-byte row segments per instruction.
+  constexpr int RPB = 256 / C;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / C;
+  const int c = threadIdx.x % C;
+  const bool valid = row < N;
+  const int64_t off = valid ? row * C + c : 0;
+  const int64_t code = valid ? idx[row] : 0;
+  const float zr = valid ? z[off] : 0.f;
+  const float er = valid ? E[code * C + c] : 0.f;
+  const float znv = valid ? zn[off] : 0.f;
+  const float zqv = valid ? zq[off] : 0.f;
+  const float go = valid ? g_out[off] : 0.f;
+  const float coef = g_loss[0] * 2.f / (float)((double)N * C);
+
+  const float dzn = go + coef * beta * (znv - zqv);
+  const float dzq = coef * (zqv - znv);
+  float nz = zr * zr, ne = er * er, pz = znv * dzn, pq = zqv * dzq;
+#pragma unroll
+  for (int o = C / 2; o >= 1; o >>= 1) {
+    nz += __shfl_xor(nz, o, 64);
+    ne += __shfl_xor(ne, o, 64);
+    pz += __shfl_xor(pz, o, 64);
+    pq += __shfl_xor(pq, o, 64);
+  }
+  nz = sqrtf(nz);
+  ne = sqrtf(ne);
+  // y = x / max(|x|, eps): Jacobian (I - y y^T)/|x| above the clamp, I/eps below it
+  const float gz = (nz > EPS) ? (dzn - znv * pz) / nz : dzn / EPS;
+  const float ge = (ne > EPS) ? (dzq - zqv * pq) / ne : dzq / EPS;
+  if (valid) {
+    dz[off] = gz;
+    atomicAdd(dE + code * C + c, ge);
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+template <int C>
+__global__ __launch_bounds__(256) void vq_gather_kernel(const int64_t* __restrict__ idx, const float* __restrict__ E,
+                                                        int64_t N, float* __restrict__ out) {
+  constexpr int LPR = C / 4;
+  const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  const int c = (threadIdx.x % LPR) * 4;
+  float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < N) e = ld4(E + idx[row] * C + c);
+  float ss = e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
+#pragma unroll
+  for (int o = LPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  const float denom = fmaxf(sqrtf(ss), EPS);
+  if (row < N) st4(out + row * C + c, make_float4(e.x / denom, e.y / denom, e.z / denom, e.w / denom));
+}
+
+// ---------------------------------------------------------------------------------------
+template <int C>
+int launch_fwd(const float* z, const float* E, int64_t N, int K, int nsplit, float* en, float* ee, float* pmin,
+               int32_t* pidx, int64_t* idx, float* out, float* zq, float* zn, float* sqerr, hipStream_t st) {
+  constexpr int LPR = C / 4;
+  hipLaunchKernelGGL(vq_prep_codebook_kernel<C>, dim3((K + 256 / LPR - 1) / (256 / LPR)), dim3(256), 0, st, E, K, en, ee);
+  const int64_t nrb = (N + ROWS_WG - 1) / ROWS_WG;
+  hipLaunchKernelGGL(vq_argmin_kernel<C>, dim3((unsigned)(nrb * nsplit)), dim3(256), 0, st, z, en, ee, N, K, nsplit, zn,
+                     pmin, pidx);
+  hipLaunchKernelGGL(vq_finalize_kernel<C>, dim3((unsigned)((N + FIN_ROWS - 1) / FIN_ROWS)), dim3(FIN_ROWS * LPR), 0, st,
+                     E, zn, pmin, pidx, N, nsplit, idx, out, zq, sqerr);
+  return 0;
+}
+
+}  // namespace amk_vq
+
+using namespace amk_vq;
+
+extern "C" int64_t amk_vq_num_partials(int64_t N) { return (N + FIN_ROWS - 1) / FIN_ROWS; }
+
+static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int amk_vq_lookup_fwd(const float* z, const float* codebook, int64_t N, int K, int C, int nsplit,
+                                 float* en_ws, float* ee_ws, float* pmin_ws, int32_t* pidx_ws,
+                                 int64_t* idx, float* out, float* zq, float* zn, float* sqerr_partial,
+                                 void* stream) {
+  AMK_CHECK_ARG(z && codebook && en_ws && ee_ws && pmin_ws && pidx_ws && idx && out && zq && zn && sqerr_partial,
+                "amk_vq_lookup_fwd: null pointer");
+  AMK_CHECK_ARG(N > 0 && K > 0 && nsplit > 0, "amk_vq_lookup_fwd: non-positive size N=%lld K=%d nsplit=%d", (long long)N, K, nsplit);
+  AMK_CHECK_SUPPORTED(C == 32 || C == 64, "amk_vq_lookup_fwd: codebook_dim %d not supported (32 or 64)", C);
+  AMK_CHECK_SUPPORTED(K % (32 * nsplit) == 0, "amk_vq_lookup_fwd: K=%d must be a multiple of 32*nsplit=%d", K, 32 * nsplit);
+  AMK_CHECK_ARG(a16(z) && a16(codebook) && a16(en_ws) && a16(out) && a16(zq) && a16(zn), "amk_vq_lookup_fwd: pointers must be 16-byte aligned");
+  const int64_t nwg = ((N + ROWS_WG - 1) / ROWS_WG) * nsplit;
+  AMK_CHECK_SUPPORTED(nwg < (1ll << 31) && (N + FIN_ROWS - 1) / FIN_ROWS < (1ll << 31), "amk_vq_lookup_fwd: grid too large");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (C == 32) launch_fwd<32>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  else launch_fwd<64>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  AMK_CHECK_LAUNCH("amk_vq_lookup_fwd");
+  return AMK_OK;
+}
+
+extern "C" int amk_vq_lookup_bwd(const float* z, const float* codebook, const float* zn, const float* zq,
+                                 const int64_t* idx, const float* g_out, const float* g_loss, float beta,
+                                 int64_t N, int K, int C, float* dz, float* dcodebook, void* stream) {
+  AMK_CHECK_ARG(z && codebook && zn && zq && idx && g_out && g_loss && dz && dcodebook, "amk_vq_lookup_bwd: null pointer");
+  AMK_CHECK_ARG(N > 0 && K > 0, "amk_vq_lookup_bwd: non-positive size");
+  AMK_CHECK_SUPPORTED(C == 32 || C == 64, "amk_vq_lookup_bwd: codebook_dim %d not supported (32 or 64)", C);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(dcodebook, 0, (size_t)K * C * sizeof(float), st) != hipSuccess) {
+    amk_set_error("amk_vq_lookup_bwd: hipMemsetAsync failed");
+    return AMK_ELAUNCH;
+  }
+  const int rpb = 256 / C;
+  const int64_t nb = (N + rpb - 1) / rpb;
+  AMK_CHECK_SUPPORTED(nb < (1ll << 31), "amk_vq_lookup_bwd: grid too large");
+  if (C == 32)
+    hipLaunchKernelGGL(vq_bwd_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
+  else
+    hipLaunchKernelGGL(vq_bwd_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
+  AMK_CHECK_LAUNCH("amk_vq_lookup_bwd");
+  return AMK_OK;
+}
+
+extern "C" int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, int C, float* out, void* stream) {
+  AMK_CHECK_ARG(idx && codebook && out, "amk_vq_gather: null pointer");
+  AMK_CHECK_ARG(N > 0 && K > 0, "amk_vq_gather: non-positive size");
+  AMK_CHECK_SUPPORTED(C == 32 || C == 64, "amk_vq_gather: codebook_dim %d not supported (32 or 64)", C);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpb = 256 / (C / 4);
+  const int64_t nb = (N + rpb - 1) / rpb;
+  AMK_CHECK_SUPPORTED(nb < (1ll << 31), "amk_vq_gather: grid too large");
+  if (C == 32) hipLaunchKernelGGL(vq_gather_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
+  else hipLaunchKernelGGL(vq_gather_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
+  AMK_CHECK_LAUNCH("amk_vq_gather");
+  return AMK_OK;
+}

@@ -1,0 +1,137 @@
+/*
+ * amk.h -- C ABI of libamk.so: the MI355X (gfx950 / CDNA4) kernels behind the
+ * attention / MoE / VQ hot path of pranoyr/attention-models.
+ *
+ * The reference has no FFI: its hot path is five Python nn.Modules (SURVEY.md
+ * section 8b).  This header is the boundary a maintainer binds instead of the
+ * eager-PyTorch op sequences inside those modules; every entry point cites the
+ * reference lines it replaces.  The Python binding that ships with this repo is
+ * attention-models_amd/amk/lib.py (ctypes); INTEGRATION.md shows the stub.
+ *
+ * Contract (all entry points)
+ *   - extern "C", plain pointers and sizes; no C++ / torch types cross the ABI.
+ *   - every pointer is a DEVICE pointer (hipMalloc'ed, fp32 unless stated),
+ *     allocated and owned by the caller; the library never allocates, frees or
+ *     synchronises.  Workspaces are caller-allocated, sizes stated per function.
+ *   - launches are asynchronous on `stream` (a hipStream_t passed as void*;
+ *     NULL = the default stream).
+ *   - return value: AMK_OK (0) or a negative AMK_E* code; amk_last_error()
+ *     returns a thread-local message for the last failure on this thread.
+ *   - tensors are row-major; "stride" arguments are in ELEMENTS, the innermost
+ *     (head-dim / feature) axis is always contiguous.
+ *   - indices are int64 where the reference returns torch.int64.
+ */
+#ifndef AMK_H_
+#define AMK_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMK_VERSION 100 /* 0.1.0 */
+
+enum {
+  AMK_OK = 0,
+  AMK_EINVAL = -1,       /* bad argument (null pointer, non-positive size, ...) */
+  AMK_EUNSUPPORTED = -2, /* shape outside what the kernels are built for        */
+  AMK_ELAUNCH = -3       /* hipLaunchKernel / hipMemsetAsync reported an error  */
+};
+
+int amk_version(void);
+/* Offload architecture the code objects were built for ("gfx950"). */
+const char* amk_arch(void);
+const char* amk_last_error(void);
+
+/* --------------------------------------------------------------------------
+ * Fused softmax attention core.
+ * Replaces models/softmax_attention.py:62-76 (and the identical core of
+ * models/switchhead_attention.py:98-111): scaled QK^T, key-padding fill,
+ * causal fill, row softmax, PV -- without materialising the (B,h,I,J) scores.
+ *
+ *   S[b,h,i,j] = sum_d (q[b,h,i,d]*scale) * k[b,h,j,d]
+ *   S = -1e9 where key_mask[b,j] == 0          (reference: masked_fill(~context_mask))
+ *   S = -1e9 where causal_mask[i,j] != 0       (reference: masked_fill(causal_mask))
+ *   P = softmax_j(S);  o[b,h,i,:] = sum_j P[b,h,i,j] v[b,h,j,:]
+ *   stats[b,h,i] = { m, l }: m = max_j S*log2(e), l = sum_j exp2(S*log2(e) - m)
+ *                 (saved for the backward; two floats per row so that a fully
+ *                  masked row, S = -1e9 everywhere, keeps its exact 1/J weights)
+ *
+ * q/o are addressed as  base + b*sb + t*st + h*sh + d   (d < D contiguous), so
+ * the (B,T,h*D) projection outputs are consumed in place (st = h*D, sh = D) as
+ * well as (B,h,T,D) tensors (sh = T*D, st = D).  k and v likewise with J rows.
+ * key_mask: uint8 (B,J) contiguous or NULL; causal_mask: uint8 (I,J) contiguous
+ * or NULL.  stats: (B,H,I,2) contiguous.  D must be 64.
+ * -------------------------------------------------------------------------- */
+int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float* stats,
+                 const uint8_t* key_mask, const uint8_t* causal_mask,
+                 int B, int H, int I, int J, int D,
+                 int64_t q_sb, int64_t q_st, int64_t q_sh,
+                 int64_t k_sb, int64_t k_st, int64_t k_sh,
+                 int64_t v_sb, int64_t v_st, int64_t v_sh,
+                 int64_t o_sb, int64_t o_st, int64_t o_sh,
+                 float scale, void* stream);
+
+/* Backward of amk_attn_fwd (autograd of the same reference lines).
+ * Inputs: q,k,v,o,stats as in the forward, d_o (gradient of o, same addressing
+ * as o with its own strides).  Outputs: dq (q-like), dk (k-like), dv (v-like),
+ * each fully overwritten.  delta_ws: workspace of B*H*I floats.
+ * Gradients do not flow through filled (-1e9) positions, as in masked_fill. */
+int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
+                 const float* stats, const float* d_o,
+                 float* dq, float* dk, float* dv, float* delta_ws,
+                 const uint8_t* key_mask, const uint8_t* causal_mask,
+                 int B, int H, int I, int J, int D,
+                 int64_t q_sb, int64_t q_st, int64_t q_sh,
+                 int64_t k_sb, int64_t k_st, int64_t k_sh,
+                 int64_t v_sb, int64_t v_st, int64_t v_sh,
+                 int64_t o_sb, int64_t o_st, int64_t o_sh,
+                 int64_t do_sb, int64_t do_st, int64_t do_sh,
+                 int64_t dq_sb, int64_t dq_st, int64_t dq_sh,
+                 int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
+                 int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
+                 float scale, void* stream);
+
+/* --------------------------------------------------------------------------
+ * VQ codebook nearest-neighbour lookup.
+ * Replaces models/vitvqgan.py:151-171 (Codebook.forward) and :16-17 (l2_norm).
+ *
+ *   zn = z / max(||z||, 1e-12)                   (N,C)
+ *   en = E / max(||E||, 1e-12)                   (K,C)
+ *   dist[n,k] = (sum zn[n]^2 + sum en[k]^2) - 2 * <zn[n], en[k]>
+ *   idx[n] = argmin_k dist[n,k]                  (first minimum on ties)
+ *   zq[n]  = E[idx[n]] / max(||E[idx[n]]||, 1e-12)
+ *   out[n] = zn[n] + (zq[n] - zn[n])             (straight-through value)
+ *   sqerr_partial[w] = partial sums of (zq - zn)^2 ; the caller forms
+ *        loss = (1 + beta) * sum(sqerr_partial) / (N*C)
+ *
+ * C must be 32 or 64.  nsplit >= 1 splits the codebook over workgroups; K must
+ * be a multiple of 32*nsplit.  Workspaces: en_ws K*C floats, ee_ws K floats,
+ * pmin_ws N*nsplit floats, pidx_ws N*nsplit int32.  sqerr_partial holds
+ * amk_vq_num_partials(N) floats.  The distance matrix is never written to HBM.
+ * -------------------------------------------------------------------------- */
+int64_t amk_vq_num_partials(int64_t N);
+int amk_vq_lookup_fwd(const float* z, const float* codebook, int64_t N, int K, int C, int nsplit,
+                      float* en_ws, float* ee_ws, float* pmin_ws, int32_t* pidx_ws,
+                      int64_t* idx, float* out, float* zq, float* zn, float* sqerr_partial,
+                      void* stream);
+
+/* Backward of Codebook.forward (autograd of models/vitvqgan.py:151-171).
+ *   g_out (N,C): gradient of `out`; g_loss: DEVICE pointer to the scalar
+ *   gradient of the loss.  dz (N,C) is overwritten; dcodebook (K,C) is zeroed
+ *   here and then scatter-added by idx.
+ *   dzn = g_out + g_loss*2*beta*(zn - zq)/(N*C);   dz = J_norm(z)^T dzn
+ *   dzq = g_loss*2*(zq - zn)/(N*C);  dE[idx[n]] += J_norm(E[idx[n]])^T dzq */
+int amk_vq_lookup_bwd(const float* z, const float* codebook, const float* zn, const float* zq,
+                      const int64_t* idx, const float* g_out, const float* g_loss, float beta,
+                      int64_t N, int K, int C, float* dz, float* dcodebook, void* stream);
+
+/* Codebook.indices_to_embeddings (models/vitvqgan.py:173-176): out[n] = l2norm(E[idx[n]]). */
+int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, int C,
+                  float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMK_H_ */

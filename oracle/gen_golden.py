@@ -1,0 +1,321 @@
+"""Generate tests/golden/*.npz by running the REFERENCE's own source files on the CPU.
+
+Runs only in the build container (the reference checkout is not present on the GPU box):
+
+    python oracle/gen_golden.py            # writes tests/golden/*.npz + golden_meta.json
+
+The reference modules are loaded from /root/reference/models/*.py by path through a namespace
+stub for the ``models`` package (its __init__ imports torchvision/cv2, which are not installed;
+SURVEY.md section 8c).  Nothing from the reference is copied: the fixtures hold inputs,
+parameters and the outputs / gradients / indices the reference computes for them.
+
+One documented patch: the reference's ViT-VQGAN FeedForward cannot be constructed at HEAD
+(models/vitvqgan.py:20-34 calls object.__init__ with SwiGLU-style keywords), so the generator
+substitutes an FFN with the SwiGLU semantics those keywords describe.
+Attention and codebook fixtures do not depend on it.
+"""
+import importlib
+import json
+import os
+import sys
+import time
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+REF = os.environ.get("AMK_REFERENCE", "/root/reference")
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def load_reference():
+    pkg = types.ModuleType("models")
+    pkg.__path__ = [os.path.join(REF, "models")]
+    sys.modules["models"] = pkg
+    mods = {}
+    for name in ("softmax_attention", "agent_attention", "switchhead_attention", "moe", "vitvqgan"):
+        mods[name] = importlib.import_module(f"models.{name}")
+    pkg.SwitchHeadAttention = mods["switchhead_attention"].SwitchHeadAttention
+    pkg.MoELayer = mods["moe"].MoELayer
+    mods["vit_moe"] = importlib.import_module("models.vit_moe")
+    return mods
+
+
+from fixture_recipe import randomize_, seeded  # noqa: E402
+
+
+def np_state(module):
+    return {"w:" + k: v.detach().numpy().copy() for k, v in module.state_dict().items()}
+
+
+def grads_of(out, cot, wrt):
+    gs = torch.autograd.grad((out * cot).sum(), wrt, allow_unused=True)
+    return [None if g is None else g.detach().numpy().copy() for g in gs]
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    clean = {k: v for k, v in arrays.items() if v is not None}
+    np.savez_compressed(path, **clean)
+    return os.path.getsize(path)
+
+
+# ----------------------------------------------------------------------------------------
+def gen_softmax_attention(mods, meta):
+    SA = mods["softmax_attention"].SoftmaxAttention
+    dim, h, d, B, T, J = 96, 2, 64, 2, 40, 77
+    m = SA(dim, h, d)
+    randomize_(m, 11)
+    x = seeded((B, T, dim), 101).requires_grad_(True)
+    ctx = seeded((B, J, dim), 102).requires_grad_(True)
+    cot = seeded((B, T, dim), 103)
+    causal = torch.ones(T, T).triu(1).bool()
+    keymask = torch.ones(B, T, dtype=torch.bool)
+    keymask[0, -9:] = False
+    keymask[1, :5] = False
+    ctxmask = torch.ones(B, J, dtype=torch.bool)
+    ctxmask[:, -17:] = False
+    # a causal mask with one fully masked query row (uniform softmax over all keys)
+    dead = causal.clone()
+    dead[3, :] = True
+    params = [p for _, p in sorted(m.named_parameters())]
+    pnames = [n for n, _ in sorted(m.named_parameters())]
+    arrays = dict(np_state(m), x=x.detach().numpy(), context=ctx.detach().numpy(), cot=cot.numpy(),
+                  causal=causal.numpy(), keymask=keymask.numpy(), ctxmask=ctxmask.numpy(), dead=dead.numpy(),
+                  dims=np.array([dim, h, d]))
+    variants = {
+        "self": dict(),
+        "self_keymask": dict(context_mask=keymask),
+        "self_causal": dict(causal_mask=causal),
+        "self_both": dict(causal_mask=causal, context_mask=keymask),
+        "self_deadrow": dict(causal_mask=dead),
+        "cross": dict(context=ctx),
+        "cross_ctxmask": dict(context=ctx, context_mask=ctxmask),
+    }
+    for vname, kw in variants.items():
+        out = m(x, **kw)
+        wrt = [x] + ([ctx] if "context" in kw else []) + params
+        gs = grads_of(out, cot, wrt)
+        arrays[f"{vname}:out"] = out.detach().numpy()
+        arrays[f"{vname}:gx"] = gs[0]
+        off = 1
+        if "context" in kw:
+            arrays[f"{vname}:gctx"] = gs[1]
+            off = 2
+        for n, g in zip(pnames, gs[off:]):
+            arrays[f"{vname}:g:{n}"] = g
+    meta["softmax_attention"] = dict(bytes=save("softmax_attention", **arrays), variants=list(variants))
+
+    # BASELINE.json configs[0]: dim 512, h 16, d 64, (B 2, T 128); weights/inputs from seeds,
+    # outputs stored for every 4th token.
+    dim, h, d, B, T = 512, 16, 64, 2, 128
+    m = SA(dim, h, d)
+    randomize_(m, 12)
+    x = seeded((B, T, dim), 201).requires_grad_(True)
+    cot = seeded((B, T, dim), 202)
+    out = m(x)
+    gx, = grads_of(out, cot, [x])
+    t0 = time.perf_counter()
+    for _ in range(5):
+        o2 = m(x)
+        torch.autograd.grad((o2 * cot).sum(), [x] + list(m.parameters()))
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    meta["softmax_attention_c1"] = dict(
+        bytes=save("softmax_attention_c1", out_s4=out.detach().numpy()[:, ::4], gx_s4=gx[:, ::4],
+                   dims=np.array([dim, h, d, B, T]), seeds=np.array([12, 201, 202])),
+        ref_cpu_ms_fwd_bwd=ms)
+
+
+def gen_codebook(mods, meta):
+    CB = mods["vitvqgan"].Codebook
+    # small, everything stored
+    K, C, B, T = 512, 32, 2, 24
+    cb = CB(K, C)
+    with torch.no_grad():
+        cb.embedding.weight.copy_(seeded((K, C), 301))
+    z = seeded((B, T, C), 302).requires_grad_(True)
+    cot = seeded((B, T, C), 303)
+    zq, idx, loss = cb(z)
+    gz, gE = torch.autograd.grad((zq * cot).sum() + 3.0 * loss, [z, cb.embedding.weight])
+    with torch.no_grad():
+        zf = F.normalize(z, dim=-1).view(-1, C)
+        en = F.normalize(cb.embedding.weight, dim=-1)
+        dist = zf.pow(2).sum(1, keepdim=True) + en.pow(2).sum(1) - 2 * zf @ en.t()
+        two = torch.topk(dist, 2, dim=1, largest=False).values
+        margin = (two[:, 1] - two[:, 0]).numpy()
+        emb = cb.indices_to_embeddings(idx)
+    meta["codebook_small"] = dict(bytes=save(
+        "codebook_small", E=cb.embedding.weight.detach().numpy(), z=z.detach().numpy(), cot=cot.numpy(),
+        zq=zq.detach().numpy(), idx=idx.numpy(), loss=loss.detach().numpy(), gz=gz.numpy(), gE=gE.numpy(),
+        margin=margin, emb=emb.detach().numpy(), loss_weight=np.array(3.0)))
+
+    # config C3 shape: K 8192, C 32, N = 2*1024; codebook and z from seeds, indices stored
+    K, C, B, T = 8192, 32, 2, 1024
+    cb = CB(K, C)
+    with torch.no_grad():
+        cb.embedding.weight.copy_(seeded((K, C), 311))
+    z = seeded((B, T, C), 312)
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        zq, idx, loss = cb(z)
+        ms = (time.perf_counter() - t0) * 1e3
+        zf = F.normalize(z, dim=-1).view(-1, C)
+        en = F.normalize(cb.embedding.weight, dim=-1)
+        dist = zf.pow(2).sum(1, keepdim=True) + en.pow(2).sum(1) - 2 * zf @ en.t()
+        two = torch.topk(dist, 2, dim=1, largest=False).values
+        margin = (two[:, 1] - two[:, 0]).numpy()
+    meta["codebook_c3"] = dict(bytes=save(
+        "codebook_c3", idx=idx.numpy().astype(np.int16), loss=loss.numpy(), margin=margin.astype(np.float32),
+        zq_sum=zq.double().sum().numpy(), dims=np.array([K, C, B, T]), seeds=np.array([311, 312])),
+        ref_cpu_ms_fwd=ms, min_margin=float(margin.min()))
+
+
+class _SwiGLU(nn.Module):
+    def __init__(self, in_features, hidden_features, out_features, bias=True):
+        super().__init__()
+        self.w12 = nn.Linear(in_features, 2 * hidden_features, bias=bias)
+        self.w3 = nn.Linear(hidden_features, out_features, bias=bias)
+
+    def forward(self, x):
+        a, b = self.w12(x).chunk(2, dim=-1)
+        return self.w3(F.silu(a) * b)
+
+
+class _PatchedFeedForward(_SwiGLU):
+    """Stands in for the unconstructible reference FeedForward (see module docstring)."""
+
+    def __init__(self, in_features, hidden_features=None, bias=True):
+        hidden = (int(hidden_features * 2 / 3) + 7) // 8 * 8
+        super().__init__(in_features=in_features, hidden_features=hidden, out_features=in_features, bias=bias)
+
+
+def gen_vitvqgan(mods, meta):
+    vv = mods["vitvqgan"]
+    vv.FeedForward = _PatchedFeedForward
+    cfg = dict(dim=64, img_size=32, patch_size=4, n_heads=2, d_head=64, depth=2, mlp_dim=96, dropout=0.0)
+    cbp = dict(codebook_size=256, codebook_dim=32)
+    m = vv.ViTVQGAN(cfg, cbp)
+    randomize_(m, 21)
+    with torch.no_grad():
+        m.codebook.embedding.weight.copy_(seeded((256, 32), 401))
+        m.encoder.pos_enc.copy_(seeded(m.encoder.pos_enc.shape, 402, 0.5))
+        m.decoder.pos_enc.copy_(seeded(m.decoder.pos_enc.shape, 403, 0.5))
+    g = torch.Generator().manual_seed(404)
+    imgs = torch.rand(2, 3, 32, 32, generator=g)
+    rec, loss = m(imgs)
+    idx = m.encode_imgs(imgs)
+    total = F.mse_loss(rec, imgs) + F.l1_loss(rec, imgs) + loss
+    names = [n for n, _ in sorted(m.named_parameters())]
+    gs = torch.autograd.grad(total, [p for _, p in sorted(m.named_parameters())], allow_unused=True)
+    with torch.no_grad():
+        dec = m.decode_indices(idx)
+        z = m.pre_quant(m.encoder(imgs))
+        zf = F.normalize(z, dim=-1).view(-1, 32)
+        en = F.normalize(m.codebook.embedding.weight, dim=-1)
+        dist = zf.pow(2).sum(1, keepdim=True) + en.pow(2).sum(1) - 2 * zf @ en.t()
+        two = torch.topk(dist, 2, dim=1, largest=False).values
+        margin = (two[:, 1] - two[:, 0]).numpy()
+    arrays = dict(np_state(m), imgs=imgs.numpy(), rec=rec.detach().numpy(), loss=loss.detach().numpy(),
+                  idx=idx.numpy(), dec=dec.numpy(), z=z.numpy(), margin=margin, total=total.detach().numpy())
+    for n, gr in zip(names, gs):
+        if gr is not None:
+            arrays["g:" + n] = gr.numpy()
+    meta["vitvqgan_small"] = dict(bytes=save("vitvqgan_small", **arrays), cfg=cfg, codebook=cbp,
+                                  n_params=sum(p.numel() for p in m.parameters()))
+
+
+def gen_moe(mods, meta):
+    Moe = mods["moe"].MoELayer
+    D, E, k, B, T = 64, 6, 2, 2, 10
+    m = Moe(D, D, E, k)
+    randomize_(m, 31)
+    x = seeded((B, T, D), 501).requires_grad_(True)
+    cot = seeded((B, T, D), 502)
+    out = m(x)
+    with torch.no_grad():
+        logits = m.gate(x)
+        wts, sel = torch.topk(logits, k)
+        srt = torch.sort(logits, dim=-1, descending=True).values
+        gap = (srt[..., k - 1] - srt[..., k]).numpy()
+    params = [p for _, p in sorted(m.named_parameters())]
+    pnames = [n for n, _ in sorted(m.named_parameters())]
+    gs = grads_of(out, cot, [x] + params)
+    arrays = dict(np_state(m), x=x.detach().numpy(), cot=cot.numpy(), out=out.detach().numpy(), sel=sel.numpy(),
+                  gap=gap, gx=gs[0], dims=np.array([D, E, k]))
+    for n, g in zip(pnames, gs[1:]):
+        arrays["g:" + n] = g
+    meta["moe_small"] = dict(bytes=save("moe_small", **arrays))
+
+
+def gen_switchhead(mods, meta):
+    SH = mods["switchhead_attention"].SwitchHeadAttention
+    dim, h, d, E, k, B, T = 96, 2, 64, 5, 2, 2, 10
+    m = SH(dim, h, d, num_experts=E, sel_experts=k)
+    randomize_(m, 41)
+    x = seeded((B, T, dim), 601).requires_grad_(True)
+    cot = seeded((B, T, dim), 602)
+    keymask = torch.ones(B, T, dtype=torch.bool)
+    keymask[0, -3:] = False
+    params = [p for _, p in sorted(m.named_parameters())]
+    pnames = [n for n, _ in sorted(m.named_parameters())]
+    arrays = dict(np_state(m), x=x.detach().numpy(), cot=cot.numpy(), keymask=keymask.numpy(),
+                  dims=np.array([dim, h, d, E, k]))
+    with torch.no_grad():
+        arrays["sel_v"] = torch.topk(m.W_s(x), k).indices.numpy()
+        arrays["sel_o"] = torch.topk(m.W_d(x), k).indices.numpy()
+    for vname, kw in {"self": {}, "self_keymask": dict(context_mask=keymask)}.items():
+        out = m(x, **kw)
+        gs = grads_of(out, cot, [x] + params)
+        arrays[f"{vname}:out"] = out.detach().numpy()
+        arrays[f"{vname}:gx"] = gs[0]
+        for n, g in zip(pnames, gs[1:]):
+            arrays[f"{vname}:g:{n}"] = g  # W_d.0.weight has no gradient (None -> not stored)
+    meta["switchhead_small"] = dict(bytes=save("switchhead_small", **arrays))
+
+
+def gen_agent(mods, meta):
+    AA = mods["agent_attention"].AgentAttention
+    dim, h, d, agent_num, B, T = 96, 3, 64, 9, 2, 20   # pool = int(9**0.5) = 3 == h
+    m = AA(dim, h, d, agent_num=agent_num)
+    randomize_(m, 51)
+    with torch.no_grad():
+        m.bias1.fill_(0.3)
+        m.bias2.fill_(-0.2)
+    x = seeded((B, T, dim), 701).requires_grad_(True)
+    cot = seeded((B, T, dim), 702)
+    out = m(x)
+    params = [p for _, p in sorted(m.named_parameters())]
+    pnames = [n for n, _ in sorted(m.named_parameters())]
+    gs = grads_of(out, cot, [x] + params)
+    arrays = dict(np_state(m), x=x.detach().numpy(), cot=cot.numpy(), out=out.detach().numpy(), gx=gs[0],
+                  dims=np.array([dim, h, d, agent_num]))
+    for n, g in zip(pnames, gs[1:]):
+        arrays["g:" + n] = g
+    meta["agent_small"] = dict(bytes=save("agent_small", **arrays))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(os.cpu_count() or 1)
+    mods = load_reference()
+    meta = dict(torch=torch.__version__, threads=torch.get_num_threads(), cpu_count=os.cpu_count(),
+                reference=REF, generated_by="oracle/gen_golden.py")
+    gen_softmax_attention(mods, meta)
+    gen_codebook(mods, meta)
+    gen_vitvqgan(mods, meta)
+    gen_moe(mods, meta)
+    gen_switchhead(mods, meta)
+    gen_agent(mods, meta)
+    with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
+        json.dump(meta, f, indent=1, sort_keys=True)
+    total = sum(v["bytes"] for v in meta.values() if isinstance(v, dict) and "bytes" in v)
+    print(json.dumps(meta, indent=1, sort_keys=True))
+    print(f"total fixture bytes: {total}")
+
+
+if __name__ == "__main__":
+    main()
