@@ -91,11 +91,12 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale):
     return q, k, v, o, stats
 
 
-def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, scale):
+def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, scale, stages=7, delta=None):
     B, H, I, D = q.shape
     J = k.shape[2]
     d_o = _as_kernel_view(d_o)
-    delta = torch.empty((B, H, I), device=q.device, dtype=torch.float32)
+    if delta is None:
+        delta = torch.empty((B, H, I), device=q.device, dtype=torch.float32)
     L = _lib.load()
     rc = L.amk_attn_bwd(
         _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(d_o),
@@ -103,7 +104,7 @@ def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, sc
         B, H, I, J, D,
         *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o), *_strides4(d_o),
         *_strides4(dq), *_strides4(dk), *_strides4(dv),
-        float(scale), _stream(),
+        float(scale), int(stages), _stream(),
     )
     _lib.check(rc, "amk_attn_bwd")
 

@@ -383,7 +383,7 @@ extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, cons
                             int64_t dq_sb, int64_t dq_st, int64_t dq_sh,
                             int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
                             int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
-                            float scale, void* stream) {
+                            float scale, int stages, void* stream) {
   AMK_CHECK_ARG(q && k && v && o && stats && d_o && dq && dk && dv && delta_ws, "amk_attn_bwd: null tensor pointer");
   AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_bwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
   AMK_CHECK_SUPPORTED(Dh == D, "amk_attn_bwd: head dim %d not supported (built for %d)", Dh, D);
@@ -405,13 +405,15 @@ extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, cons
   const int64_t nq = (int64_t)B * H * p.nqblk, nk = (int64_t)B * H * p.nkblk;
   AMK_CHECK_SUPPORTED(nq < (1ll << 31) && nk < (1ll << 31) && (nrow + 15) / 16 < (1ll << 31), "amk_attn_bwd: grid too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, st, p);
-  if (causal_mask) {
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3((unsigned)nk), dim3(WG), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)nq), dim3(WG), 0, st, p);
-  } else {
-    hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3((unsigned)nk), dim3(WG), 0, st, p);
-    hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)nq), dim3(WG), 0, st, p);
+  if (stages & AMK_ATTN_BWD_DELTA)
+    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, st, p);
+  if (stages & AMK_ATTN_BWD_DKDV) {
+    if (causal_mask) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3((unsigned)nk), dim3(WG), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3((unsigned)nk), dim3(WG), 0, st, p);
+  }
+  if (stages & AMK_ATTN_BWD_DQ) {
+    if (causal_mask) hipLaunchKernelGGL(attn_bwd_dq_kernel<true>, dim3((unsigned)nq), dim3(WG), 0, st, p);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel<false>, dim3((unsigned)nq), dim3(WG), 0, st, p);
   }
   AMK_CHECK_LAUNCH("amk_attn_bwd");
   return AMK_OK;

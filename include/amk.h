@@ -77,7 +77,14 @@ int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float
  * Inputs: q,k,v,o,stats as in the forward, d_o (gradient of o, same addressing
  * as o with its own strides).  Outputs: dq (q-like), dk (k-like), dv (v-like),
  * each fully overwritten.  delta_ws: workspace of B*H*I floats.
- * Gradients do not flow through filled (-1e9) positions, as in masked_fill. */
+ * Gradients do not flow through filled (-1e9) positions, as in masked_fill.
+ * `stages` selects the launches (bit 0: delta = rowsum(dO*O) into delta_ws, bit 1: dK/dV,
+ * bit 2: dQ); pass AMK_ATTN_BWD_ALL.  Profilers time one stage by passing its bit alone
+ * (bits 1 and 2 read delta_ws, so bit 0 must have run before). */
+#define AMK_ATTN_BWD_DELTA 1
+#define AMK_ATTN_BWD_DKDV 2
+#define AMK_ATTN_BWD_DQ 4
+#define AMK_ATTN_BWD_ALL 7
 int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  const float* stats, const float* d_o,
                  float* dq, float* dk, float* dv, float* delta_ws,
@@ -91,7 +98,7 @@ int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  int64_t dq_sb, int64_t dq_st, int64_t dq_sh,
                  int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
                  int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
-                 float scale, void* stream);
+                 float scale, int stages, void* stream);
 
 /* --------------------------------------------------------------------------
  * VQ codebook nearest-neighbour lookup.

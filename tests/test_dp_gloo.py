@@ -1,0 +1,112 @@
+"""GradReducer (amk/dp.py) on two CPU processes over gloo: the N>1 path of bench.py.
+
+Checks against a single-process computation of the same global batch: averaged gradients,
+parameters with no gradient (the reference's SwitchHead W_d case), gradient accumulation
+(sync=False micro-steps) and identical parameters after optimizer steps on both ranks.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.b = nn.Linear(16, 4)
+        self.unused = nn.Linear(3, 3)  # never reached: no gradient in any step
+
+    def forward(self, x):
+        return self.b(torch.tanh(self.a(x)))
+
+
+def _data(rank_count=2, per_rank=5):
+    g = torch.Generator().manual_seed(7)
+    return torch.randn(rank_count * per_rank, 8, generator=g), torch.randn(rank_count * per_rank, 4, generator=g)
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "attention-models_amd"))
+    from amk.dp import GradReducer
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)  # deliberately different init: broadcast must fix it
+    net = Net()
+    red = GradReducer(net.parameters(), bucket_bytes=256)  # tiny buckets -> several of them
+    red.broadcast_parameters()
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    x, y = _data(world)
+    xs, ys = x.chunk(world)[rank], y.chunk(world)[rank]
+
+    # step 1: plain synchronous step
+    red.begin(sync=True)
+    ((net(xs) - ys) ** 2).mean().backward()
+    red.finish()
+    g1 = {n: p.grad.clone() for n, p in net.named_parameters()}
+    opt.step()
+    red.zero_grad()
+    # steps 2+3: accumulate two micro-batches, communicate on the second only
+    h = xs.shape[0] // 2
+    red.begin(sync=False)
+    (((net(xs[:h]) - ys[:h]) ** 2).mean() / 2).backward()
+    red.finish()
+    red.begin(sync=True)
+    (((net(xs[h:2 * h]) - ys[h:2 * h]) ** 2).mean() / 2).backward()
+    red.finish()
+    g2 = {n: p.grad.clone() for n, p in net.named_parameters()}
+    opt.step()
+    red.zero_grad()
+    torch.save(dict(g1=g1, g2=g2, params={n: p.detach().clone() for n, p in net.named_parameters()},
+                    nbuckets=len(red.buckets)), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.timeout(120)
+def test_two_rank_reducer_matches_single_process(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "rank1.pt", weights_only=True)
+    assert r0["nbuckets"] > 1
+
+    # single-process reference: rank 0's initial weights, mean over ranks of per-rank losses
+    torch.manual_seed(100)
+    net = Net()
+    x, y = _data(world)
+    loss = sum(((net(xs) - ys) ** 2).mean() for xs, ys in zip(x.chunk(world), y.chunk(world))) / world
+    loss.backward()
+    for n, p in net.named_parameters():
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(r0["g1"][n], want, atol=1e-6), n
+        assert torch.equal(r0["g1"][n], r1["g1"][n]), n
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    opt.step()
+    opt.zero_grad()
+    h = x.chunk(world)[0].shape[0] // 2
+    loss = 0
+    for xs, ys in zip(x.chunk(world), y.chunk(world)):
+        loss = loss + (((net(xs[:h]) - ys[:h]) ** 2).mean() / 2 + ((net(xs[h:2 * h]) - ys[h:2 * h]) ** 2).mean() / 2)
+    (loss / world).backward()
+    for n, p in net.named_parameters():
+        want = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert torch.allclose(r0["g2"][n], want, atol=1e-6), n
+    opt.step()
+    for n, p in net.named_parameters():
+        assert torch.allclose(r0["params"][n], p, atol=1e-6), n
+        assert torch.equal(r0["params"][n], r1["params"][n]), n
