@@ -50,6 +50,14 @@ def parse():
     return ap.parse_args()
 
 
+T_START = time.perf_counter()
+
+
+def note(msg):
+    """Progress to stderr (stdout carries only the JSON line)."""
+    print(f"[bench +{time.perf_counter() - T_START:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def time_launches(fn, iters, warm=3):
     """Average duration (s) of fn()'s launches, HIP events on the current (launch) stream."""
     for _ in range(warm):
@@ -136,9 +144,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note(f"rank {rank}/{world}: model built, batch {args.batch}/GPU")
     for _ in range(args.warmup):
         trainer.step(imgs)
     sync()
+    note("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         logs = trainer.step(imgs)
@@ -149,16 +159,19 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     loss = float(logs["loss"])
+    note(f"timed {args.steps} steps in {dt:.3f}s")
 
     kernels = None
     if rank == 0 and not args.no_kernels:
         kernels = kernel_rooflines(args.batch, dev, args.kernel_iters)
+        note("kernel rooflines done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import train_step_cpu
 
         ips, cores, sample = train_step_cpu.time_train_step(init_state, VIT, NLayerDiscriminator(3, 64, 3))
         cpu = dict(value=ips, unit="images/s", cores=cores, kind="port", sample=sample)
+        note("cpu baseline done")
 
     if rank == 0:
         global_batch = args.batch * world

@@ -41,12 +41,25 @@ def _step(w, names, cfg, discr, g_opt, d_opt, img, adv_w=0.1, laplace_w=1.0, max
     torch.nn.utils.clip_grad_norm_(params, max_norm)
     g_opt.step()
     g_opt.zero_grad()
-    return float(loss)
+    return float(loss.detach())
 
 
-def time_train_step(state_dict, cfg, discr, batch=2, steps=2, warmup=1, threads=None):
-    """Returns (images_per_sec, threads_used, description of the sample)."""
-    threads = threads or os.cpu_count() or 1
+def host_cores():
+    """Cores this process may really use: cgroup quota, then affinity, then cpu_count."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def time_train_step(state_dict, cfg, discr, batch=2, steps=2, warmup=1, threads=None, budget_s=30.0):
+    """Returns (images_per_sec, threads_used, description of the sample).  The sample is
+    bounded: if the warm-up step alone shows `steps` would exceed budget_s, fewer are timed."""
+    threads = threads or min(host_cores(), 32)
     torch.set_num_threads(threads)
     w = {k: v.detach().clone().float().cpu() for k, v in state_dict.items()}
     names = sorted(w)
@@ -57,8 +70,12 @@ def time_train_step(state_dict, cfg, discr, batch=2, steps=2, warmup=1, threads=
     d_opt = torch.optim.Adam(discr.parameters(), lr=1e-4)
     g = torch.Generator().manual_seed(1234)
     img = torch.rand(batch, 3, cfg["img_size"], cfg["img_size"], generator=g)
+    t0 = time.perf_counter()
     for _ in range(warmup):
         _step(w, names, cfg, discr, g_opt, d_opt, img)
+    if warmup:
+        per = (time.perf_counter() - t0) / warmup
+        steps = max(1, min(steps, int(budget_s / max(per, 1e-3))))
     t0 = time.perf_counter()
     for _ in range(steps):
         _step(w, names, cfg, discr, g_opt, d_opt, img)
