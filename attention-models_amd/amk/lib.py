@@ -31,6 +31,12 @@ SIGNATURES = {
     "amk_vq_lookup_fwd": (_I, [_P, _P, _L, _I, _I, _I] + [_P] * 9 + [_P]),
     "amk_vq_lookup_bwd": (_I, [_P] * 7 + [_F, _L, _I, _I, _P, _P, _P]),
     "amk_vq_gather": (_I, [_P, _P, _L, _I, _I, _P, _P]),
+    "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 7),
+    "amk_grouped_gemm_nt": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "amk_grouped_gemm_nn": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "amk_grouped_gemm_wgrad": (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
+    "amk_moe_combine": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "amk_moe_gate_grad": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
 }
 
 _lib = None

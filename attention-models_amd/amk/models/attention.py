@@ -3,10 +3,12 @@ signatures and state_dict keys, with the score / softmax / PV arithmetic in liba
 
 SoftmaxAttention mirrors /root/reference/models/softmax_attention.py:22-82.
 """
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .moe import StackedExpertsMixin, linear_like_init_
 
 
 class SoftmaxAttention(nn.Module):
@@ -43,3 +45,66 @@ class SoftmaxAttention(nn.Module):
             key_mask=context_mask, causal_mask=causal_mask,
         )                                # (B, I, h*d) == 'b h t d -> b t (h d)'
         return self._drop(self.W_o(o))
+
+
+class SwitchHeadAttention(StackedExpertsMixin, nn.Module):
+    """SwitchHead attention (reference: models/switchhead_attention.py:18-116).
+
+    Dense Q and K projections; the V projection and the output projection are mixtures of E
+    experts routed PER (token, head): ``moe_v`` weights its top-k experts with
+    sigmoid(W_s logits); ``moe_out`` routes with the W_d logits but sums its experts
+    UN-weighted, so W_d receives no gradient (reference :80-87).
+    The experts are shared by all heads; heads are summed at the end.  No output bias.
+
+    state_dict keys: q.0.weight, k.0.weight, W_s.0.weight, W_d.0.weight,
+    experts_v.{e}.weight (d, dim), experts_out.{e}.weight (dim, d).
+    """
+
+    _stacked = {"experts_v_weight": ("experts_v", "weight"), "experts_out_weight": ("experts_out", "weight")}
+
+    def __init__(self, dim, num_heads=8, dim_head=64, num_experts=5, sel_experts=2, dropout=0.0):
+        super().__init__()
+        self.dim, self.num_heads, self.dim_head = dim, num_heads, dim_head
+        self.num_experts, self.sel_experts = num_experts, sel_experts
+        inner = num_heads * dim_head
+        self.q = nn.Sequential(nn.Linear(dim, inner, bias=False))
+        self.k = nn.Sequential(nn.Linear(dim, inner, bias=False))
+        self.W_s = nn.Sequential(nn.Linear(dim, num_heads * num_experts, bias=False))
+        self.experts_v_weight = nn.Parameter(torch.empty(num_experts, dim_head, dim))
+        self.W_d = nn.Sequential(nn.Linear(dim, num_heads * num_experts, bias=False))
+        self.experts_out_weight = nn.Parameter(torch.empty(num_experts, dim, dim_head))
+        linear_like_init_(self.experts_v_weight)
+        linear_like_init_(self.experts_out_weight)
+        self.dropout_p = float(dropout)
+        self.scale = dim_head ** -0.5
+        self.inf = -1e9
+        self.last_selected_v = None
+        self.last_selected_out = None
+
+    def _drop(self, t):
+        return F.dropout(t, self.dropout_p, self.training) if self.dropout_p > 0.0 else t
+
+    def forward(self, x, context=None, causal_mask=None, context_mask=None):
+        B, I, _ = x.shape
+        src = x if context is None else context
+        J = src.shape[1]
+        if J != I:
+            # the reference indexes moe_out rows by the CONTEXT positions and returns (B, J, dim)
+            # for J != I (SURVEY.md section 0.6); no caller uses it (models/vit_moe.py:34 is self).
+            raise NotImplementedError("SwitchHeadAttention with a context of another length is a reference quirk, not supported")
+        h, d, E, k = self.num_heads, self.dim_head, self.num_experts, self.sel_experts
+        q = self._drop(self.q(x)).view(B, I, h, d).permute(0, 2, 1, 3)
+        kk = self._drop(self.k(src)).view(B, J, h, d).permute(0, 2, 1, 3)
+        src2 = src.reshape(B * J, self.dim)
+        # moe_v: unit = (b, t, head); every unit reads the token's full input row
+        v, sel_v = ops.routed_linear(src2, self.W_s(src).reshape(B * J * h, E), self.experts_v_weight, None,
+                                     k, x_div=h * k, weighted=True, outer=1)
+        v = v.view(B, J, h, d).permute(0, 2, 1, 3)
+        o = ops.attention(q, kk, v, self.scale, key_mask=context_mask, causal_mask=causal_mask)  # (B,h,I,d)
+        o2 = o.permute(0, 2, 1, 3).reshape(B * I * h, d)  # 'b i h d' rows, contiguous by construction
+        # moe_out: routed by W_d(gate_inputs = src), experts summed un-weighted, then summed over heads
+        out, sel_o = ops.routed_linear(o2, self.W_d(src).reshape(B * J * h, E), self.experts_out_weight, None,
+                                       k, x_div=k, weighted=False, outer=h)
+        self.last_selected_v = sel_v.view(B, J, h, k)
+        self.last_selected_out = sel_o.view(B, J, h, k)
+        return out.view(B, I, self.dim)

@@ -275,3 +275,95 @@ def vq_gather(indices, codebook):
     rc = L.amk_vq_gather(_ptr(flat), _ptr(codebook.detach().contiguous()), N, K, C, _ptr(out), _stream())
     _lib.check(rc, "amk_vq_gather")
     return out.view(*indices.shape, C)
+
+
+# ---------------------------------------------------------------------------- routed experts
+def _i32(n, dev):
+    return torch.empty((n,), device=dev, dtype=torch.int32)
+
+
+def moe_route(logits2, k):
+    """logits2 (U,E) -> dict(ids int64 (U,k), gate (U,k), offsets int32 (E+1), perm int32 (U*k))."""
+    _require_device(logits2)
+    U, E = logits2.shape
+    dev = logits2.device
+    ids = torch.empty((U, k), device=dev, dtype=torch.int64)
+    gate = torch.empty((U, k), device=dev, dtype=torch.float32)
+    counts, rank = _i32(E, dev), _i32(U * k, dev)
+    offsets, perm = _i32(E + 1, dev), _i32(U * k, dev)
+    L = _lib.load()
+    rc = L.amk_moe_route(_ptr(logits2.contiguous()), U, E, k, _ptr(ids), _ptr(gate), _ptr(counts), _ptr(rank),
+                         _ptr(offsets), _ptr(perm), _stream())
+    _lib.check(rc, "amk_moe_route")
+    return dict(ids=ids, gate=gate, offsets=offsets, perm=perm)
+
+
+class _RoutedLinear(torch.autograd.Function):
+    """Top-k routed expert Linear + ordered combine, one launch per stage for ALL experts.
+
+    x2 (Rx,Kd); logits2 (U,E) with U*k pairs, pair p reads x row p // x_div; W (E,N,Kd);
+    bias (E,N) or None.  out[g] = sum over the `outer` units of group g and their k slots (in
+    ascending expert id) of gate*expert(x) (weighted) or expert(x) (un-weighted, SwitchHead
+    moe_out).  Returns (out (U/outer, N), ids (U,k) int64)."""
+
+    @staticmethod
+    def forward(ctx, x2, logits2, W, bias, k, x_div, weighted, outer):
+        _require_device(x2, logits2, W, bias)
+        x2 = x2.contiguous()
+        W = W.contiguous()
+        U, E = logits2.shape
+        N, Kd = W.shape[1], W.shape[2]
+        P = U * k
+        dev = x2.device
+        if x2.shape != (P // x_div, Kd) or U % outer:
+            raise RuntimeError(f"routed linear shapes disagree: x {tuple(x2.shape)} U {U} k {k} x_div {x_div} W {tuple(W.shape)}")
+        r = moe_route(logits2.detach(), k)
+        L = _lib.load()
+        Y = torch.empty((P, N), device=dev, dtype=torch.float32)
+        rc = L.amk_grouped_gemm_nt(_ptr(x2), Kd, x_div, _ptr(W), _ptr(bias), _ptr(r["offsets"]), _ptr(r["perm"]),
+                                   P, E, N, Kd, _ptr(Y), _stream())
+        _lib.check(rc, "amk_grouped_gemm_nt")
+        G = U // outer
+        out = torch.empty((G, N), device=dev, dtype=torch.float32)
+        rc = L.amk_moe_combine(_ptr(Y), _ptr(r["ids"]), _ptr(r["gate"]) if weighted else _NULL, G, outer, k, N,
+                               _ptr(out), _stream())
+        _lib.check(rc, "amk_moe_combine")
+        ctx.save_for_backward(x2, W, Y, r["ids"], r["gate"], r["offsets"], r["perm"])
+        ctx.cfg = (k, x_div, weighted, outer, E, bias is not None)
+        ctx.mark_non_differentiable(r["ids"])
+        return out, r["ids"]
+
+    @staticmethod
+    def backward(ctx, d_out, _d_ids):
+        x2, W, Y, ids, gate, offsets, perm = ctx.saved_tensors
+        k, x_div, weighted, outer, E, has_bias = ctx.cfg
+        N, Kd = W.shape[1], W.shape[2]
+        P = ids.numel()
+        U = P // k
+        dev = x2.device
+        d_out = d_out.contiguous()
+        g_div = outer * k
+        scale = _ptr(gate) if weighted else _NULL
+        L = _lib.load()
+        dlogits = None
+        if weighted:
+            dlogits = torch.empty((U, E), device=dev, dtype=torch.float32)
+            rc = L.amk_moe_gate_grad(_ptr(d_out), _ptr(Y), _ptr(ids), _ptr(gate), P, k, E, N, g_div, _ptr(dlogits), _stream())
+            _lib.check(rc, "amk_moe_gate_grad")
+        dxp = torch.empty((P, Kd), device=dev, dtype=torch.float32)
+        rc = L.amk_grouped_gemm_nn(_ptr(d_out), N, g_div, _ptr(W), scale, _ptr(offsets), _ptr(perm), P, E, N, Kd,
+                                   _ptr(dxp), _stream())
+        _lib.check(rc, "amk_grouped_gemm_nn")
+        dx = torch.empty_like(x2)
+        rc = L.amk_moe_combine(_ptr(dxp), _ptr(ids), _NULL, x2.shape[0], x_div // k, k, Kd, _ptr(dx), _stream())
+        _lib.check(rc, "amk_moe_combine")
+        dW = torch.empty_like(W)
+        db = torch.empty((E, N), device=dev, dtype=torch.float32) if has_bias else None
+        rc = L.amk_grouped_gemm_wgrad(_ptr(d_out), N, g_div, _ptr(x2), Kd, x_div, scale, _ptr(offsets), _ptr(perm),
+                                      P, E, N, Kd, _ptr(dW), _ptr(db), _stream())
+        _lib.check(rc, "amk_grouped_gemm_wgrad")
+        return dx, dlogits, dW, db, None, None, None, None
+
+
+def routed_linear(x2, logits2, W, bias, k, x_div, weighted=True, outer=1):
+    return _RoutedLinear.apply(x2, logits2, W, bias, k, x_div, weighted, outer)

@@ -1,0 +1,489 @@
+// Top-k expert routing and grouped expert GEMMs for gfx950 (exact-f32 MFMA).
+//
+// Replaces the per-expert Python loops of the reference -- MoELayer.forward
+// (models/moe.py:23-38) and SwitchHeadAttention.moe_v / moe_out
+// (models/switchhead_attention.py:58-88): for each expert a torch.where (host sync), a
+// gather, a small GEMM and an index_put.  Here routing is three tiny launches with no host
+// sync and every expert's GEMM runs in ONE launch:
+//
+//   route_topk     : per routed unit (a token, or a (token, head)), top-k of its E gate logits
+//                    (descending, lowest index on ties = torch.topk on distinct values) and
+//                    sigmoid of the selected logits.
+//   route_rank     : one wave per expert scans the ids with ballots: counts[e] and each pair's
+//                    rank inside its expert, in ascending pair order (deterministic).
+//   route_perm     : exclusive scan of the counts -> offsets[E+1]; perm[offsets[e]+rank] = pair.
+//   grouped_nt     : Y[p,:]  = A[p/a_div,:] * W_e^T (+ b_e)          (forward of x W^T + b)
+//   grouped_nn     : Y[p,:]  = s[p] * (A[p/a_div,:] * W_e)           (input gradient)
+//   grouped_wgrad  : dW_e    = sum_{p in e} s[p] * G[p/a_div,:]^T (x) X[p/b_div,:]  (+ db_e)
+//   combine        : out[g]  = sum_outer ( sum_{slots, ascending expert id} s[p] * Y[p] )
+//   gate_grad      : dlogit[u, ids[p]] = sigmoid'(.) * <dOut[p/g_div], Y[p]>
+//
+// A "pair" p = unit*k + slot.  Tiles are 64 pairs x 64 outputs x 32 deep, 4 waves, one 32x32
+// accumulator per wave with the OUTPUT FEATURE ON THE LANE (coalesced 128-B row segments on
+// store, per-lane bias), operands through LDS with row stride 36 / 68 floats (conflict-free
+// ds_read_b128 row reads, ds_read_b32 column reads).
+#include "amk_common.h"
+
+namespace amk_moe {
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ float f4(const float4& v, int e) {
+  return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
+}
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+constexpr int MAX_K = 8;
+
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict__ logits, int64_t U, int E, int k,
+                                                         int64_t* __restrict__ ids, float* __restrict__ gate) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= U) return;
+  const float* lg = logits + u * E;
+  int chosen[MAX_K];
+#pragma unroll 1
+  for (int s = 0; s < k; ++s) {
+    float best = -INFINITY;
+    int bi = -1;
+    for (int e = 0; e < E; ++e) {
+      bool taken = false;
+      for (int j = 0; j < s; ++j) taken |= (chosen[j] == e);
+      const float v = lg[e];
+      if (!taken && (bi < 0 || v > best)) { best = v; bi = e; }
+    }
+    chosen[s] = bi;
+    ids[u * k + s] = bi;
+    gate[u * k + s] = 1.f / (1.f + expf(-best));
+  }
+}
+
+__global__ __launch_bounds__(64) void route_rank_kernel(const int64_t* __restrict__ ids, int64_t P,
+                                                        int32_t* __restrict__ counts, int32_t* __restrict__ rank) {
+  const int e = blockIdx.x;
+  const int lane = threadIdx.x;
+  int base = 0;
+  for (int64_t p0 = 0; p0 < P; p0 += 64) {
+    const int64_t p = p0 + lane;
+    const bool hit = (p < P) && (ids[p] == e);
+    const unsigned long long m = __ballot(hit);
+    if (hit) rank[p] = base + __popcll(m & ((1ull << lane) - 1ull));
+    base += __popcll(m);
+  }
+  if (lane == 0) counts[e] = base;
+}
+
+__global__ __launch_bounds__(256) void route_perm_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ counts,
+                                                         const int32_t* __restrict__ rank, int64_t P, int E,
+                                                         int32_t* __restrict__ offsets, int32_t* __restrict__ perm) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    int acc = 0;
+    for (int e = 0; e < E; ++e) { offsets[e] = acc; acc += counts[e]; }
+    offsets[E] = acc;
+  }
+  if (p >= P) return;
+  const int e = (int)ids[p];
+  int off = 0;
+  for (int j = 0; j < e; ++j) off += counts[j];
+  perm[off + rank[p]] = (int)p;
+}
+
+// ---------------------------------------------------------------------------------------
+struct GemmParams {
+  const float* A;        // rows addressed A + (p / a_div) * lda
+  const float* B2;       // wgrad only: rows addressed B2 + (p / b_div) * ldb
+  const float* W;        // (E, N, Kd) contiguous
+  const float* bias;     // (E, N) or null            (nt)
+  const float* scale;    // (P) or null               (nn, wgrad)
+  float* Y;              // (P, N) for nt, (P, Kd) for nn; dW (E, N, Kd) for wgrad
+  float* dbias;          // (E, N) or null            (wgrad)
+  const int32_t* offsets;
+  const int32_t* perm;
+  int E, N, Kd;
+  int a_div, b_div;
+  int64_t lda, ldb;
+};
+
+// Locate (expert, m-tile) for this workgroup: tiles are dealt expert by expert.
+__device__ __forceinline__ bool find_tile(const int32_t* offsets, int E, int tile, int& e, int& m0, int& cnt) {
+  for (int j = 0; j < E; ++j) {
+    const int c = offsets[j + 1] - offsets[j];
+    const int nt = (c + 63) >> 6;
+    if (tile < nt) { e = j; m0 = tile * 64; cnt = c; return true; }
+    tile -= nt;
+  }
+  return false;
+}
+
+// Y[p, n] = sum_kk A[arow(p), kk] * W[e, n, kk] (+ bias[e, n])
+__global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
+  constexpr int LS = 36;
+  __shared__ __attribute__((aligned(16))) float smem[2 * 64 * LS];
+  __shared__ int prow[64];
+  float* As = smem;
+  float* Ws = smem + 64 * LS;
+  int e, m0, cnt;
+  if (!find_tile(g.offsets, g.E, blockIdx.x, e, m0, cnt)) return;
+  const int n0 = blockIdx.y * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
+  __syncthreads();
+  const float* We = g.W + (int64_t)e * g.N * g.Kd;
+
+  // staging: 64 rows x 32 floats = 512 float4 per operand, 2 per thread
+  const int sr = tid >> 3, sc = (tid & 7) * 4;  // rows sr, sr+32
+  const int pa = prow[sr], pb = prow[sr + 32];
+  const float* arow0 = pa >= 0 ? g.A + (int64_t)(pa / g.a_div) * g.lda : nullptr;
+  const float* arow1 = pb >= 0 ? g.A + (int64_t)(pb / g.a_div) * g.lda : nullptr;
+  const float* wrow0 = (n0 + sr < g.N) ? We + (int64_t)(n0 + sr) * g.Kd : nullptr;
+  const float* wrow1 = (n0 + sr + 32 < g.N) ? We + (int64_t)(n0 + sr + 32) * g.Kd : nullptr;
+  float4 a0, a1, w0, w1;
+  auto prefetch = [&](int k0) {
+    const bool kin = k0 + sc < g.Kd;
+    a0 = (arow0 && kin) ? ld4(arow0 + k0 + sc) : zero4();
+    a1 = (arow1 && kin) ? ld4(arow1 + k0 + sc) : zero4();
+    w0 = (wrow0 && kin) ? ld4(wrow0 + k0 + sc) : zero4();
+    w1 = (wrow1 && kin) ? ld4(wrow1 + k0 + sc) : zero4();
+  };
+  auto commit = [&]() {
+    st4(&As[sr * LS + sc], a0);
+    st4(&As[(sr + 32) * LS + sc], a1);
+    st4(&Ws[sr * LS + sc], w0);
+    st4(&Ws[(sr + 32) * LS + sc], w1);
+  };
+  f32x16 acc = zero16();
+  prefetch(0);
+  for (int k0 = 0; k0 < g.Kd; k0 += 32) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (k0 + 32 < g.Kd) prefetch(k0 + 32);
+    const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
+    const float* wr = &Ws[(32 * wn + ln) * LS + 16 * hf];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 a = ld4(ar + 4 * s4);
+      const float4 b = ld4(wr + 4 * s4);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) acc = mfma32(f4(a, x), f4(b, x), acc);
+    }
+  }
+  const int n = n0 + 32 * wn + ln;
+  if (n < g.N) {
+    const float bv = g.bias ? g.bias[(int64_t)e * g.N + n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = prow[32 * wm + acc_row(r, hf)];
+      if (p >= 0) g.Y[(int64_t)p * g.N + n] = acc[r] + bv;
+    }
+  }
+}
+
+// Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk]
+__global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
+  constexpr int LS = 36, WS = 68;
+  __shared__ __attribute__((aligned(16))) float smem[64 * LS + 32 * WS];
+  __shared__ int prow[64];
+  float* As = smem;            // [64 pairs][32 n]
+  float* Ws = smem + 64 * LS;  // [32 n][64 kk]
+  int e, m0, cnt;
+  if (!find_tile(g.offsets, g.E, blockIdx.x, e, m0, cnt)) return;
+  const int c0 = blockIdx.y * 64;  // output (kk) tile
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
+  __syncthreads();
+  const float* We = g.W + (int64_t)e * g.N * g.Kd;
+
+  const int sr = tid >> 3, sc = (tid & 7) * 4;    // A: rows sr, sr+32; cols sc
+  const int wr_ = tid >> 4, wc = (tid & 15) * 4;  // W: rows wr_, wr_+16 (n); cols wc (kk)
+  const int pa = prow[sr], pb = prow[sr + 32];
+  const float* arow0 = pa >= 0 ? g.A + (int64_t)(pa / g.a_div) * g.lda : nullptr;
+  const float* arow1 = pb >= 0 ? g.A + (int64_t)(pb / g.a_div) * g.lda : nullptr;
+  const bool cin = c0 + wc < g.Kd;
+  float4 a0, a1, w0, w1;
+  auto prefetch = [&](int nb) {
+    const bool nin = nb + sc < g.N;
+    a0 = (arow0 && nin) ? ld4(arow0 + nb + sc) : zero4();
+    a1 = (arow1 && nin) ? ld4(arow1 + nb + sc) : zero4();
+    w0 = (cin && nb + wr_ < g.N) ? ld4(We + (int64_t)(nb + wr_) * g.Kd + c0 + wc) : zero4();
+    w1 = (cin && nb + wr_ + 16 < g.N) ? ld4(We + (int64_t)(nb + wr_ + 16) * g.Kd + c0 + wc) : zero4();
+  };
+  auto commit = [&]() {
+    st4(&As[sr * LS + sc], a0);
+    st4(&As[(sr + 32) * LS + sc], a1);
+    st4(&Ws[wr_ * WS + wc], w0);
+    st4(&Ws[(wr_ + 16) * WS + wc], w1);
+  };
+  f32x16 acc = zero16();
+  prefetch(0);
+  for (int nb = 0; nb < g.N; nb += 32) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (nb + 32 < g.N) prefetch(nb + 32);
+    const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
+    const float* wc_ = &Ws[(16 * hf) * WS + 32 * wn + ln];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      const float4 a = ld4(ar + 4 * s4);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) acc = mfma32(f4(a, x), wc_[(4 * s4 + x) * WS], acc);
+    }
+  }
+  const int c = c0 + 32 * wn + ln;
+  if (c < g.Kd) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int p = prow[32 * wm + acc_row(r, hf)];
+      if (p >= 0) g.Y[(int64_t)p * g.Kd + c] = acc[r] * (g.scale ? g.scale[p] : 1.f);
+    }
+  }
+}
+
+// dW[e, n, kk] = sum_{p in e} scale[p] * G[p/a_div, n] * X[p/b_div, kk] ; dbias[e, n] = sum_p scale[p] * G[.., n]
+__global__ __launch_bounds__(256, 2) void grouped_wgrad_kernel(GemmParams g) {
+  constexpr int WS = 68;
+  __shared__ __attribute__((aligned(16))) float smem[2 * 32 * WS];
+  float* Gs = smem;            // [32 pairs][64 n]   (already scaled)
+  float* Xs = smem + 32 * WS;  // [32 pairs][64 kk]
+  const int e = blockIdx.z;
+  const int n0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int beg = g.offsets[e], cnt = g.offsets[e + 1] - beg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;  // wm: n half, wn: kk half
+  const int sr = tid >> 4, sc = (tid & 15) * 4;  // rows sr, sr+16 (pairs); cols sc
+  float4 g0, g1, x0, x1;
+  auto prefetch = [&](int m) {
+    const int ia = m + sr, ib = m + sr + 16;
+    g0 = g1 = x0 = x1 = zero4();
+    if (ia < cnt) {
+      const int p = g.perm[beg + ia];
+      const float s = g.scale ? g.scale[p] : 1.f;
+      if (n0 + sc < g.N) { g0 = ld4(g.A + (int64_t)(p / g.a_div) * g.lda + n0 + sc); g0.x *= s; g0.y *= s; g0.z *= s; g0.w *= s; }
+      if (c0 + sc < g.Kd) x0 = ld4(g.B2 + (int64_t)(p / g.b_div) * g.ldb + c0 + sc);
+    }
+    if (ib < cnt) {
+      const int p = g.perm[beg + ib];
+      const float s = g.scale ? g.scale[p] : 1.f;
+      if (n0 + sc < g.N) { g1 = ld4(g.A + (int64_t)(p / g.a_div) * g.lda + n0 + sc); g1.x *= s; g1.y *= s; g1.z *= s; g1.w *= s; }
+      if (c0 + sc < g.Kd) x1 = ld4(g.B2 + (int64_t)(p / g.b_div) * g.ldb + c0 + sc);
+    }
+  };
+  auto commit = [&]() {
+    st4(&Gs[sr * WS + sc], g0);
+    st4(&Gs[(sr + 16) * WS + sc], g1);
+    st4(&Xs[sr * WS + sc], x0);
+    st4(&Xs[(sr + 16) * WS + sc], x1);
+  };
+  f32x16 acc = zero16();
+  float bsum = 0.f;
+  if (cnt > 0) prefetch(0);
+  for (int m = 0; m < cnt; m += 32) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (m + 32 < cnt) prefetch(m + 32);
+    const float* gc = &Gs[(16 * hf) * WS + 32 * wm + ln];
+    const float* xc = &Xs[(16 * hf) * WS + 32 * wn + ln];
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const float gv = gc[s * WS];
+      acc = mfma32(gv, xc[s * WS], acc);
+      bsum += gv;
+    }
+  }
+  const int c = c0 + 32 * wn + ln;
+  if (c < g.Kd) {
+    float* dW = g.Y + (int64_t)e * g.N * g.Kd;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int n = n0 + 32 * wm + acc_row(r, hf);
+      if (n < g.N) dW[(int64_t)n * g.Kd + c] = acc[r];
+    }
+  }
+  if (g.dbias && blockIdx.x == 0 && wn == 0) {
+    bsum += __shfl_xor(bsum, 32, 64);
+    const int n = n0 + 32 * wm + ln;
+    if (hf == 0 && n < g.N) g.dbias[(int64_t)e * g.N + n] = bsum;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// out[g, :] = sum_{o < outer} ( sum over the k slots of unit (g*outer+o), ascending expert id,
+//             of scale[p] * Y[p, :] )     -- the accumulation order of the reference loops.
+__global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ Y, const int64_t* __restrict__ ids,
+                                                      const float* __restrict__ scale, int64_t G, int outer, int k,
+                                                      int N, float* __restrict__ out) {
+  const int nv = N >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= G * nv) return;
+  const int64_t gi = idx / nv;
+  const int c = (int)(idx % nv) * 4;
+  float4 tot = zero4();
+  for (int o = 0; o < outer; ++o) {
+    const int64_t u = gi * outer + o;
+    int order[MAX_K];
+    for (int s = 0; s < k; ++s) order[s] = s;
+    for (int a = 1; a < k; ++a)  // insertion sort of the slots by expert id
+      for (int b = a; b > 0 && ids[u * k + order[b]] < ids[u * k + order[b - 1]]; --b) {
+        const int t = order[b]; order[b] = order[b - 1]; order[b - 1] = t;
+      }
+    float4 acc = zero4();
+    for (int s = 0; s < k; ++s) {
+      const int64_t p = u * k + order[s];
+      const float w = scale ? scale[p] : 1.f;
+      const float4 y = ld4(Y + p * N + c);
+      // res += w * y with separate rounding of the product, as the eager reference does
+      acc.x = __fadd_rn(acc.x, __fmul_rn(w, y.x));
+      acc.y = __fadd_rn(acc.y, __fmul_rn(w, y.y));
+      acc.z = __fadd_rn(acc.z, __fmul_rn(w, y.z));
+      acc.w = __fadd_rn(acc.w, __fmul_rn(w, y.w));
+    }
+    if (outer == 1) { tot = acc; }
+    else { tot.x += acc.x; tot.y += acc.y; tot.z += acc.z; tot.w += acc.w; }
+  }
+  st4(out + gi * N + c, tot);
+}
+
+// dlogits[u, ids[p]] = gate[p]*(1-gate[p]) * <dOut[p / g_div, :], Y[p, :]>   (dlogits zeroed by the caller side)
+__global__ __launch_bounds__(256) void gate_grad_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
+                                                        const int64_t* __restrict__ ids, const float* __restrict__ gate,
+                                                        int64_t P, int k, int E, int N, int g_div,
+                                                        float* __restrict__ dlogits) {
+  // 16 lanes per pair
+  const int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int l = threadIdx.x & 15;
+  float acc = 0.f;
+  if (p < P) {
+    const float* a = dOut + (p / g_div) * N;
+    const float* y = Y + p * N;
+    for (int c = l * 4; c < N; c += 64) {
+      const float4 u = ld4(a + c), v = ld4(y + c);
+      acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    }
+  }
+  acc += __shfl_xor(acc, 8, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 1, 64);
+  if (p < P && l == 0) {
+    const float gt = gate[p];
+    dlogits[(p / k) * E + ids[p]] = acc * gt * (1.f - gt);
+  }
+}
+
+}  // namespace amk_moe
+
+using namespace amk_moe;
+
+static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+extern "C" int amk_moe_route(const float* logits, int64_t U, int E, int k,
+                             int64_t* ids, float* gate, int32_t* counts, int32_t* rank,
+                             int32_t* offsets, int32_t* perm, void* stream) {
+  AMK_CHECK_ARG(logits && ids && gate && counts && rank && offsets && perm, "amk_moe_route: null pointer");
+  AMK_CHECK_ARG(U > 0 && E > 0 && k > 0 && k <= E, "amk_moe_route: bad sizes U=%lld E=%d k=%d", (long long)U, E, k);
+  AMK_CHECK_SUPPORTED(k <= MAX_K, "amk_moe_route: sel_experts %d > %d", k, MAX_K);
+  const int64_t P = U * k;
+  AMK_CHECK_SUPPORTED(P < (1ll << 31), "amk_moe_route: too many routed pairs");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipLaunchKernelGGL(route_topk_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, logits, U, E, k, ids, gate);
+  hipLaunchKernelGGL(route_rank_kernel, dim3(E), dim3(64), 0, st, ids, P, counts, rank);
+  hipLaunchKernelGGL(route_perm_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, ids, counts, rank, P, E, offsets, perm);
+  AMK_CHECK_LAUNCH("amk_moe_route");
+  return AMK_OK;
+}
+
+static int check_gemm(const char* who, const void* A, const void* W, const void* Y, const void* offsets, const void* perm,
+                      int64_t P, int E, int N, int Kd, int a_div, int64_t lda) {
+  if (!(A && W && Y && offsets && perm)) { amk_set_error("%s: null pointer", who); return AMK_EINVAL; }
+  if (!(P > 0 && E > 0 && N > 0 && Kd > 0 && a_div > 0)) { amk_set_error("%s: non-positive size", who); return AMK_EINVAL; }
+  if ((N % 4) || (Kd % 4) || (lda % 4) || !a16(A) || !a16(W) || !a16(Y)) {
+    amk_set_error("%s: N, Kd, lda must be multiples of 4 and pointers 16-byte aligned", who);
+    return AMK_EUNSUPPORTED;
+  }
+  if (P >= (1ll << 31)) { amk_set_error("%s: too many pairs", who); return AMK_EUNSUPPORTED; }
+  return AMK_OK;
+}
+
+extern "C" int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const float* W, const float* bias,
+                                   const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                                   float* Y, void* stream) {
+  const int rc = check_gemm("amk_grouped_gemm_nt", A, W, Y, offsets, perm, P, E, N, Kd, a_div, lda);
+  if (rc) return rc;
+  GemmParams g{};
+  g.A = A; g.W = W; g.bias = bias; g.Y = Y; g.offsets = offsets; g.perm = perm;
+  g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
+  const unsigned mt = (unsigned)((P + 63) / 64 + E);
+  hipLaunchKernelGGL(grouped_nt_kernel, dim3(mt, (N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  AMK_CHECK_LAUNCH("amk_grouped_gemm_nt");
+  return AMK_OK;
+}
+
+extern "C" int amk_grouped_gemm_nn(const float* A, int64_t lda, int a_div, const float* W, const float* scale,
+                                   const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                                   float* Y, void* stream) {
+  const int rc = check_gemm("amk_grouped_gemm_nn", A, W, Y, offsets, perm, P, E, N, Kd, a_div, lda);
+  if (rc) return rc;
+  GemmParams g{};
+  g.A = A; g.W = W; g.scale = scale; g.Y = Y; g.offsets = offsets; g.perm = perm;
+  g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
+  const unsigned mt = (unsigned)((P + 63) / 64 + E);
+  hipLaunchKernelGGL(grouped_nn_kernel, dim3(mt, (Kd + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  AMK_CHECK_LAUNCH("amk_grouped_gemm_nn");
+  return AMK_OK;
+}
+
+extern "C" int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, const float* X, int64_t ldx, int x_div,
+                                      const float* scale, const int32_t* offsets, const int32_t* perm,
+                                      int64_t P, int E, int N, int Kd, float* dW, float* dbias, void* stream) {
+  const int rc = check_gemm("amk_grouped_gemm_wgrad", G, X, dW, offsets, perm, P, E, N, Kd, g_div, ldg);
+  if (rc) return rc;
+  AMK_CHECK_ARG(x_div > 0 && (ldx % 4) == 0 && a16(X), "amk_grouped_gemm_wgrad: bad X addressing");
+  AMK_CHECK_SUPPORTED(E <= 65535 && (N + 63) / 64 <= 65535, "amk_grouped_gemm_wgrad: grid too large");
+  GemmParams g{};
+  g.A = G; g.B2 = X; g.scale = scale; g.Y = dW; g.dbias = dbias; g.offsets = offsets; g.perm = perm;
+  g.E = E; g.N = N; g.Kd = Kd; g.a_div = g_div; g.b_div = x_div; g.lda = ldg; g.ldb = ldx;
+  hipLaunchKernelGGL(grouped_wgrad_kernel, dim3((Kd + 63) / 64, (N + 63) / 64, E), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), g);
+  AMK_CHECK_LAUNCH("amk_grouped_gemm_wgrad");
+  return AMK_OK;
+}
+
+extern "C" int amk_moe_combine(const float* Y, const int64_t* ids, const float* scale, int64_t G, int outer, int k,
+                               int N, float* out, void* stream) {
+  AMK_CHECK_ARG(Y && ids && out, "amk_moe_combine: null pointer");
+  AMK_CHECK_ARG(G > 0 && outer > 0 && k > 0 && N > 0, "amk_moe_combine: non-positive size");
+  AMK_CHECK_SUPPORTED(k <= MAX_K && N % 4 == 0 && a16(Y) && a16(out), "amk_moe_combine: k <= %d, N %% 4 == 0, aligned pointers", MAX_K);
+  const int64_t n = G * (N / 4);
+  AMK_CHECK_SUPPORTED((n + 255) / 256 < (1ll << 31), "amk_moe_combine: grid too large");
+  hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     Y, ids, scale, G, outer, k, N, out);
+  AMK_CHECK_LAUNCH("amk_moe_combine");
+  return AMK_OK;
+}
+
+extern "C" int amk_moe_gate_grad(const float* d_out, const float* Y, const int64_t* ids, const float* gate,
+                                 int64_t P, int k, int E, int N, int g_div, float* dlogits, void* stream) {
+  AMK_CHECK_ARG(d_out && Y && ids && gate && dlogits, "amk_moe_gate_grad: null pointer");
+  AMK_CHECK_ARG(P > 0 && k > 0 && E > 0 && N > 0 && g_div > 0, "amk_moe_gate_grad: non-positive size");
+  AMK_CHECK_SUPPORTED(N % 4 == 0 && a16(d_out) && a16(Y), "amk_moe_gate_grad: N %% 4 == 0, aligned pointers");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (hipMemsetAsync(dlogits, 0, (size_t)(P / k) * E * sizeof(float), st) != hipSuccess) {
+    amk_set_error("amk_moe_gate_grad: hipMemsetAsync failed");
+    return AMK_ELAUNCH;
+  }
+  hipLaunchKernelGGL(gate_grad_kernel, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, st, d_out, Y, ids, gate, P, k, E, N,
+                     g_div, dlogits);
+  AMK_CHECK_LAUNCH("amk_moe_gate_grad");
+  return AMK_OK;
+}

@@ -138,6 +138,53 @@ int amk_vq_lookup_bwd(const float* z, const float* codebook, const float* zn, co
 int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, int C,
                   float* out, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Top-k expert routing and grouped expert GEMMs.
+ * Replace the per-expert Python loops (torch.where + gather + Linear + index_put) of
+ * MoELayer.forward (models/moe.py:23-38) and SwitchHeadAttention.moe_v / moe_out
+ * (models/switchhead_attention.py:58-88).  A routed "unit" u is a token (MoELayer) or a
+ * (token, head) (SwitchHead); a "pair" is p = u*k + slot.
+ * -------------------------------------------------------------------------- */
+
+/* torch.topk(logits, k) + sigmoid of the selected logits, and the expert-major ordering.
+ *   logits (U,E) -> ids int64 (U,k) descending by logit (lowest index on equal logits),
+ *   gate (U,k) = sigmoid(selected logit); offsets int32 (E+1), perm int32 (U*k): pairs grouped
+ *   by expert, ascending pair index inside an expert (deterministic).
+ *   Workspaces: counts int32 (E), rank int32 (U*k).  k <= 8. */
+int amk_moe_route(const float* logits, int64_t U, int E, int k,
+                  int64_t* ids, float* gate, int32_t* counts, int32_t* rank,
+                  int32_t* offsets, int32_t* perm, void* stream);
+
+/* Y[p,:] = A[p / a_div, :] * W[e(p)]^T (+ bias[e(p)]) for every pair: the expert Linear layers
+ * (models/moe.py:34-36, switchhead_attention.py:69-71,86).  A rows have Kd floats at stride lda;
+ * W is (E,N,Kd) contiguous, bias (E,N) or NULL, Y is (P,N).  N, Kd, lda multiples of 4. */
+int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const float* W, const float* bias,
+                        const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                        float* Y, void* stream);
+
+/* Y[p,:] = scale[p] * (A[p / a_div, :] * W[e(p)]): input gradient of the expert Linear.
+ * A rows have N floats, Y is (P,Kd); scale (P) or NULL. */
+int amk_grouped_gemm_nn(const float* A, int64_t lda, int a_div, const float* W, const float* scale,
+                        const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                        float* Y, void* stream);
+
+/* dW[e] = sum_{p in e} scale[p] * G[p / g_div, :]^T (x) X[p / x_div, :]   (E,N,Kd), fully
+ * overwritten; dbias[e] = sum_{p in e} scale[p] * G[p / g_div, :] (E,N) or NULL. */
+int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, const float* X, int64_t ldx, int x_div,
+                           const float* scale, const int32_t* offsets, const int32_t* perm,
+                           int64_t P, int E, int N, int Kd, float* dW, float* dbias, void* stream);
+
+/* out[g,:] = sum_{o<outer} ( sum over the k slots of unit g*outer+o, in ASCENDING EXPERT ID,
+ * of scale[p]*Y[p,:] ): the accumulation order of the reference loops (moe.py:32-36) and the
+ * head sum of switchhead_attention.py:115.  scale (G*outer*k) or NULL (moe_out is un-weighted). */
+int amk_moe_combine(const float* Y, const int64_t* ids, const float* scale, int64_t G, int outer, int k,
+                    int N, float* out, void* stream);
+
+/* Gradient of the gate logits through sigmoid(topk): dlogits (P/k, E) is zeroed, then
+ * dlogits[p/k, ids[p]] = gate[p]*(1-gate[p]) * <d_out[p / g_div, :], Y[p, :]>. */
+int amk_moe_gate_grad(const float* d_out, const float* Y, const int64_t* ids, const float* gate,
+                      int64_t P, int k, int E, int N, int g_div, float* dlogits, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,191 @@
+"""Routing + grouped expert GEMM kernels (through the C ABI) against the golden vectors and the
+CPU oracle: MoELayer and SwitchHeadAttention.  Expert ids must be bit-exact; values within 2e-5.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ref_cpu
+from oracle.fixture_recipe import seeded, seeded_params
+from util import assert_close, load_golden, weights_of
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _stacked_to_ref(module):
+    """state_dict of an amk module (per-expert keys, as the reference names them) on the CPU."""
+    return {k: v.detach().cpu().clone() for k, v in module.state_dict().items()}
+
+
+def test_moe_small_golden(device):
+    from amk.models import MoELayer
+
+    fx = load_golden("moe_small")
+    D, E, k = (int(v) for v in fx["dims"])
+    m = MoELayer(D, D, E, k)
+    m.load_state_dict(weights_of(fx), strict=True)
+    m = m.to(device)
+    x = torch.from_numpy(fx["x"]).to(device).requires_grad_(True)
+    out = m(x)
+    assert tuple(out.shape) == tuple(fx["out"].shape)
+    assert np.array_equal(m.last_selected_experts.cpu().numpy(), fx["sel"])  # bit-exact expert ids
+    assert_close(out, fx["out"], TOL, "out")
+    cot = torch.from_numpy(fx["cot"]).to(device)
+    (out * cot).sum().backward()
+    assert_close(x.grad, fx["gx"], TOL, "grad x")
+    assert_close(m.gate.weight.grad, fx["g:gate.weight"], TOL, "grad gate.weight")
+    assert_close(m.gate.bias.grad, fx["g:gate.bias"], TOL, "grad gate.bias")
+    for e in range(E):
+        for leaf, grad in (("weight", m.experts_weight.grad[e]), ("bias", m.experts_bias.grad[e])):
+            key = f"g:experts.{e}.{leaf}"
+            want = fx[key] if key in fx else np.zeros_like(grad.cpu().numpy())
+            assert float((grad.cpu() - torch.from_numpy(want)).abs().max()) <= TOL * max(1.0, float(np.abs(want).max())), key
+
+
+@pytest.mark.parametrize("B,T,D,E,k", [(2, 65, 1024, 32, 2), (3, 17, 128, 8, 3), (1, 1, 64, 4, 1), (2, 200, 256, 5, 2)])
+def test_moe_vs_oracle(device, B, T, D, E, k):
+    """Includes BASELINE.json configs[3] dims (D 1024, E 32, top-2, T 65)."""
+    from amk.models import MoELayer
+
+    shapes = {"gate.weight": (E, D), "gate.bias": (E,)}
+    for e in range(E):
+        shapes[f"experts.{e}.weight"] = (D, D)
+        shapes[f"experts.{e}.bias"] = (D,)
+    w = seeded_params(shapes, 60 + E)
+    x = seeded((B, T, D), 61 + T)
+    cot = seeded((B, T, D), 62 + T)
+    wr = {n: v.clone().requires_grad_(True) for n, v in w.items()}
+    xr = x.clone().requires_grad_(True)
+    out_r, sel_r = ref_cpu.moe_layer(xr, wr, E, k)
+    names = sorted(wr)
+    g_r = torch.autograd.grad((out_r * cot).sum(), [xr] + [wr[n] for n in names], allow_unused=True)
+
+    m = MoELayer(D, D, E, k)
+    m.load_state_dict(w, strict=True)
+    m = m.to(device)
+    xd = x.to(device).requires_grad_(True)
+    out = m(xd)
+    # expert ids: bit-exact wherever the k-th and (k+1)-th logits are not within rounding
+    logits = x @ w["gate.weight"].t() + w["gate.bias"]
+    srt = torch.sort(logits, dim=-1, descending=True).values
+    gap = (srt[..., :-1] - srt[..., 1:])[..., :k].min(-1).values if E > k else torch.ones(B, T)
+    sel = m.last_selected_experts.cpu()
+    bad = (sel != sel_r).any(-1)
+    assert not bool((bad & (gap > 1e-5)).any()), "expert ids differ away from logit ties"
+    assert int(bad.sum()) == 0
+    assert_close(out, out_r, TOL, "out")
+    (out * cot.to(device)).sum().backward()
+    assert_close(xd.grad, g_r[0], TOL, "grad x")
+    got = _grads_by_ref_name(m)
+    for n, g in zip(names, g_r[1:]):
+        want = g if g is not None else torch.zeros_like(w[n])
+        assert_close_abs(got[n], want, TOL, n)
+
+
+def _grads_by_ref_name(module):
+    out = {}
+    for name, p in module.named_parameters():
+        stacked = getattr(module, "_stacked", {})
+        if name in stacked:
+            mod, leaf = stacked[name]
+            for e in range(p.shape[0]):
+                out[f"{mod}.{e}.{leaf}"] = p.grad[e] if p.grad is not None else None
+        else:
+            out[name] = p.grad
+    return out
+
+
+def assert_close_abs(a, b, tol, what):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    scale = max(float(b.abs().max()), 1e-3)
+    err = float((a - b).abs().max())
+    assert err <= tol * scale * 5, f"{what}: abs err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("variant", ["self", "self_keymask"])
+def test_switchhead_small_golden(device, variant):
+    from amk.models import SwitchHeadAttention
+
+    fx = load_golden("switchhead_small")
+    dim, h, d, E, k = (int(v) for v in fx["dims"])
+    m = SwitchHeadAttention(dim, h, d, num_experts=E, sel_experts=k)
+    m.load_state_dict(weights_of(fx), strict=True)
+    m = m.to(device)
+    x = torch.from_numpy(fx["x"]).to(device).requires_grad_(True)
+    kw = {} if variant == "self" else dict(context_mask=torch.from_numpy(fx["keymask"]).to(device))
+    out = m(x, **kw)
+    assert tuple(out.shape) == tuple(fx[f"{variant}:out"].shape)
+    assert np.array_equal(m.last_selected_v.cpu().numpy(), fx["sel_v"])
+    assert np.array_equal(m.last_selected_out.cpu().numpy(), fx["sel_o"])
+    assert_close(out, fx[f"{variant}:out"], TOL, "out")
+    (out * torch.from_numpy(fx["cot"]).to(device)).sum().backward()
+    assert_close(x.grad, fx[f"{variant}:gx"], TOL, "grad x")
+    got = _grads_by_ref_name(m)
+    assert got["W_d.0.weight"] is None  # no gradient, exactly as the reference
+    for n, g in got.items():
+        key = f"{variant}:g:{n}"
+        if key in fx:
+            assert_close_abs(g, torch.from_numpy(fx[key]), TOL, n)
+
+
+@pytest.mark.parametrize("B,T,dim,h,E,k", [(2, 65, 1024, 8, 32, 2), (2, 65, 1024, 8, 5, 2), (1, 10, 512, 2, 5, 2)])
+def test_switchhead_vs_oracle(device, B, T, dim, h, E, k):
+    """ViTMoE layer dims (E 32 through the factory, E 5 standalone default) and README.md:133-142."""
+    from amk.models import SwitchHeadAttention
+
+    d = 64
+    shapes = {"q.0.weight": (h * d, dim), "k.0.weight": (h * d, dim), "W_s.0.weight": (h * E, dim), "W_d.0.weight": (h * E, dim)}
+    for e in range(E):
+        shapes[f"experts_v.{e}.weight"] = (d, dim)
+        shapes[f"experts_out.{e}.weight"] = (dim, d)
+    w = seeded_params(shapes, 70 + E)
+    x = seeded((B, T, dim), 71 + T)
+    cot = seeded((B, T, dim), 72 + T)
+    wr = {n: v.clone().requires_grad_(True) for n, v in w.items()}
+    xr = x.clone().requires_grad_(True)
+    out_r, sel_v, sel_o = ref_cpu.switchhead_attention(xr, wr, h, d, E, k)
+    names = sorted(wr)
+    g_r = torch.autograd.grad((out_r * cot).sum(), [xr] + [wr[n] for n in names], allow_unused=True)
+
+    m = SwitchHeadAttention(dim, h, d, num_experts=E, sel_experts=k)
+    m.load_state_dict(w, strict=True)
+    m = m.to(device)
+    xd = x.to(device).requires_grad_(True)
+    out = m(xd)
+    assert tuple(out.shape) == (B, T, dim)
+    assert torch.equal(m.last_selected_v.cpu(), sel_v)
+    assert torch.equal(m.last_selected_out.cpu(), sel_o)
+    assert_close(out, out_r, TOL, "out")
+    (out * cot.to(device)).sum().backward()
+    assert_close(xd.grad, g_r[0], TOL, "grad x")
+    got = _grads_by_ref_name(m)
+    for n, g in zip(names, g_r[1:]):
+        if g is None:
+            assert got[n] is None, n
+        else:
+            assert_close_abs(got[n], g, TOL, n)
+
+
+def test_routing_properties_full_size(device):
+    """At U = 64*65*8 units (ViTMoE batch 64): perm is a permutation, grouped by expert with
+    ascending pair index inside each expert, offsets match a histogram of ids, gates = sigmoid."""
+    from amk import ops
+
+    U, E, k = 64 * 65 * 8, 32, 2
+    g = torch.Generator().manual_seed(3)
+    logits = torch.randn(U, E, generator=g).to(device)
+    r = ops.moe_route(logits, k)
+    ids, gate, offsets, perm = r["ids"].cpu(), r["gate"].cpu(), r["offsets"].cpu().long(), r["perm"].cpu().long()
+    vals, ref_ids = torch.topk(logits.cpu(), k)
+    assert torch.equal(ids, ref_ids)
+    assert_close(gate, torch.sigmoid(vals), 1e-6, "gate")
+    assert torch.equal(torch.sort(perm).values, torch.arange(U * k))
+    hist = torch.bincount(ids.view(-1), minlength=E)
+    assert torch.equal(offsets[1:] - offsets[:-1], hist)
+    flat = ids.view(-1)
+    for e in range(E):
+        seg = perm[offsets[e]:offsets[e + 1]]
+        assert bool((flat[seg] == e).all())
+        assert bool((seg[1:] > seg[:-1]).all())
