@@ -108,3 +108,42 @@ class SwitchHeadAttention(StackedExpertsMixin, nn.Module):
         self.last_selected_v = sel_v.view(B, J, h, k)
         self.last_selected_out = sel_o.view(B, J, h, k)
         return out.view(B, I, self.dim)
+
+
+class AgentAttention(nn.Module):
+    """Agent attention (reference: models/agent_attention.py:21-80).
+
+    ``pool_size = int(agent_num ** 0.5)`` agent tokens per head are the adaptive average pool of
+    q over the sequence; the reference pools the (t, h) plane to (pool, pool) and therefore only
+    runs when ``num_heads == pool_size`` -- enforced here at construction.
+    ``context_mask`` is accepted and ignored, as in the reference; there is no cross mode.
+
+    state_dict keys: qkv.weight, W_o.{weight,bias}, bias1, bias2, dwc.1.{weight,bias}.
+    bias1 / bias2 are scalars added to entire softmax rows: they cannot change the output and
+    get (exactly) zero gradient; they are kept only for checkpoint compatibility.
+    """
+
+    def __init__(self, dim, num_heads=8, dim_head=64, agent_num=47, dropout=0.0):
+        super().__init__()
+        self.dim, self.num_heads, self.dim_head = dim, num_heads, dim_head
+        self.pool_size = int(agent_num ** 0.5)
+        if self.pool_size != num_heads:
+            raise ValueError(
+                f"AgentAttention needs num_heads == int(agent_num ** 0.5) (got {num_heads} vs {self.pool_size}): "
+                "the reference's einsum fails otherwise (models/agent_attention.py:56-60)")
+        inner = num_heads * dim_head
+        self.qkv = nn.Linear(dim, 3 * inner, bias=False)
+        self.scale = dim_head ** -0.5
+        self.W_o = nn.Linear(inner, dim)
+        self.dropout_p = float(dropout)
+        self.bias1 = nn.Parameter(torch.zeros(1, 1, 1, 1))
+        self.bias2 = nn.Parameter(torch.zeros(1, 1, 1, 1))
+        # index 1 of a Sequential in the reference (index 0 / 2 are einops Rearrange layers)
+        self.dwc = nn.Sequential(nn.Identity(), nn.Conv2d(dim_head, dim_head, 3, padding=1, groups=dim_head), nn.Identity())
+
+    def forward(self, x, context_mask=None):
+        conv = self.dwc[1]
+        o = ops.agent_attention(self.qkv(x), conv.weight, conv.bias, self.num_heads, self.dim_head,
+                                self.pool_size, self.scale)
+        o = self.W_o(o)
+        return F.dropout(o, self.dropout_p, self.training) if self.dropout_p > 0.0 else o

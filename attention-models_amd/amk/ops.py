@@ -367,3 +367,59 @@ class _RoutedLinear(torch.autograd.Function):
 
 def routed_linear(x2, logits2, W, bias, k, x_div, weighted=True, outer=1):
     return _RoutedLinear.apply(x2, logits2, W, bias, k, x_div, weighted, outer)
+
+
+# ---------------------------------------------------------------------------- agent attention
+class _AgentAttn(torch.autograd.Function):
+    """qkv (B,T,3*h*d) with the reference's '(qkv h d)' column order -> o (B,T,h*d)."""
+
+    @staticmethod
+    def forward(ctx, qkv2, conv_w, conv_b, H, D, P, scale):
+        _require_device(qkv2, conv_w, conv_b)
+        B, T, _ = qkv2.shape
+        qkv2 = qkv2.contiguous()
+        qkv = qkv2.view(B, T, 3, H, D)
+        q, k, v = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        dev = qkv2.device
+        o = _new_bthd(B, H, T, D, qkv2)
+        agents = torch.empty((B, H, P, D), device=dev, dtype=torch.float32)
+        vagent = torch.empty_like(agents)
+        stats1 = torch.empty((B, H, P, 2), device=dev, dtype=torch.float32)
+        cw, cb = conv_w.contiguous(), conv_b.contiguous()
+        L = _lib.load()
+        rc = L.amk_agent_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(cw), _ptr(cb), _ptr(o), _ptr(agents), _ptr(vagent),
+                                  _ptr(stats1), B, H, T, D, P, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
+                                  float(scale), _stream())
+        _lib.check(rc, "amk_agent_attn_fwd")
+        ctx.save_for_backward(qkv2, cw, agents, vagent, stats1)
+        ctx.cfg = (H, D, P, scale)
+        return o.permute(0, 2, 1, 3).reshape(B, T, H * D)
+
+    @staticmethod
+    def backward(ctx, d_o2):
+        qkv2, cw, agents, vagent, stats1 = ctx.saved_tensors
+        H, D, P, scale = ctx.cfg
+        B, T, _ = qkv2.shape
+        dev = qkv2.device
+        qkv = qkv2.view(B, T, 3, H, D)
+        q, k, v = (qkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        d_o = d_o2.contiguous().view(B, T, H, D).permute(0, 2, 1, 3)
+        dqkv2 = torch.empty_like(qkv2)
+        dqkv = dqkv2.view(B, T, 3, H, D)
+        dq, dk, dv = (dqkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
+        dag = torch.empty_like(agents)
+        dw_part = torch.empty((B * H, 9, D), device=dev, dtype=torch.float32)
+        db_part = torch.empty((B * H, D), device=dev, dtype=torch.float32)
+        L = _lib.load()
+        rc = L.amk_agent_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(cw), _ptr(d_o), _ptr(agents), _ptr(vagent), _ptr(stats1),
+                                  _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dag), _ptr(dw_part), _ptr(db_part),
+                                  B, H, T, D, P, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(d_o),
+                                  *_strides4(dq), *_strides4(dk), *_strides4(dv), float(scale), _stream())
+        _lib.check(rc, "amk_agent_attn_bwd")
+        dconv_w = dw_part.sum(0).t().reshape(D, 1, 3, 3)
+        dconv_b = db_part.sum(0)
+        return dqkv2, dconv_w, dconv_b, None, None, None, None
+
+
+def agent_attention(qkv2, conv_w, conv_b, num_heads, dim_head, pool, scale):
+    return _AgentAttn.apply(qkv2, conv_w, conv_b, num_heads, dim_head, pool, scale)

@@ -185,6 +185,39 @@ int amk_moe_combine(const float* Y, const int64_t* ids, const float* scale, int6
 int amk_moe_gate_grad(const float* d_out, const float* Y, const int64_t* ids, const float* gate,
                       int64_t P, int k, int E, int N, int g_div, float* dlogits, void* stream);
 
+/* --------------------------------------------------------------------------
+ * AgentAttention core.
+ * Replaces models/agent_attention.py:55-73: agent tokens A = adaptive average pool of q over
+ * the sequence into P bins per head (AdaptiveAvgPool2d over the (t, h) plane with
+ * h == P, the only configuration in which the reference runs -- SURVEY.md section 0.5),
+ *   V_a = softmax((A*scale) K^T) V,   O = softmax((q*scale) A^T) V_a + dwc(v)
+ * where dwc is the depthwise 3x3 convolution (weights (D,1,3,3), bias (D)) over the
+ * (head, token) plane.  The reference's scalar bias1 / bias2 are added to whole softmax rows,
+ * so they change nothing and receive zero gradient; they do not cross the ABI.
+ * q,k,v,o addressed like amk_attn_fwd (T rows).  Saved for the backward: agents (B,H,P,D),
+ * vagent (B,H,P,D), stats1 (B,H,P,2) = {row max, row sum} of the aggregation softmax.
+ * D must be 64, P <= 16, P <= T.
+ * -------------------------------------------------------------------------- */
+int amk_agent_attn_fwd(const float* q, const float* k, const float* v, const float* conv_w, const float* conv_b,
+                       float* o, float* agents, float* vagent, float* stats1,
+                       int B, int H, int T, int D, int P,
+                       int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                       int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
+                       float scale, void* stream);
+
+/* Backward of amk_agent_attn_fwd: dq, dk, dv fully overwritten (q/k/v-like addressing);
+ * dconvw_part (B*H, 9, D) and dconvb_part (B*H, D) are per-(batch, head) partial sums of the
+ * convolution weight / bias gradients (the caller sums over the first axis; weight element
+ * [c][0][a][b] is partial [.., a*3+b, c]); dagents_ws: workspace (B,H,P,D). */
+int amk_agent_attn_bwd(const float* q, const float* k, const float* v, const float* conv_w, const float* d_o,
+                       const float* agents, const float* vagent, const float* stats1,
+                       float* dq, float* dk, float* dv, float* dagents_ws, float* dconvw_part, float* dconvb_part,
+                       int B, int H, int T, int D, int P,
+                       int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                       int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t do_sb, int64_t do_st, int64_t do_sh,
+                       int64_t dq_sb, int64_t dq_st, int64_t dq_sh, int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
+                       int64_t dv_sb, int64_t dv_st, int64_t dv_sh, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
