@@ -1,7 +1,11 @@
 """Same export list as the reference's ``models`` package (models/__init__.py:1-14) for the
 classes on the hot path and their scaffolding."""
 from .attention import AgentAttention, SoftmaxAttention, SwitchHeadAttention
+from .model_factory import build_model
 from .moe import MoELayer
+from .vit import ViT
+from .vit_moe import ViTMoE
 from .vitvqgan import Codebook, ViTVQGAN
 
-__all__ = ["SoftmaxAttention", "AgentAttention", "SwitchHeadAttention", "MoELayer", "Codebook", "ViTVQGAN"]
+__all__ = ["SoftmaxAttention", "AgentAttention", "SwitchHeadAttention", "MoELayer", "Codebook", "ViTVQGAN",
+           "ViT", "ViTMoE", "build_model"]

@@ -18,7 +18,7 @@ def seeded_param(name, shape, seed, index):
         or name.endswith("to_patch_embedding.1.weight")
         or name.endswith("to_patch_embedding.3.weight")
     )
-    scale = fan ** -0.5
+    scale = max(fan, 1) ** -0.5
     if name.endswith("bias") or is_norm_weight:
         scale = 0.1
     v = seeded(shape, seed * 1000 + index, scale)

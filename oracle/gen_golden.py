@@ -36,7 +36,8 @@ def load_reference():
     pkg.__path__ = [os.path.join(REF, "models")]
     sys.modules["models"] = pkg
     mods = {}
-    for name in ("softmax_attention", "agent_attention", "switchhead_attention", "moe", "vitvqgan"):
+    for name in ("softmax_attention", "agent_attention", "switchhead_attention", "moe", "vitvqgan", "positional_encoding",
+                 "transformer", "vit"):
         mods[name] = importlib.import_module(f"models.{name}")
     pkg.SwitchHeadAttention = mods["switchhead_attention"].SwitchHeadAttention
     pkg.MoELayer = mods["moe"].MoELayer
@@ -297,6 +298,46 @@ def gen_agent(mods, meta):
     meta["agent_small"] = dict(bytes=save("agent_small", **arrays))
 
 
+def gen_vit(mods, meta):
+    cfg = dict(dim=64, image_size=32, patch_size=8, n_heads=2, d_head=64, depth=2, mlp_dim=128, dropout=0.0, num_classes=10)
+    m = mods["vit"].ViT(**cfg)
+    randomize_(m, 61)
+    g = torch.Generator().manual_seed(801)
+    imgs = torch.randn(2, 3, 32, 32, generator=g)
+    labels = torch.tensor([3, 7])
+    logits = m(imgs)
+    loss = F.cross_entropy(logits, labels)
+    names = [n for n, _ in sorted(m.named_parameters())]
+    gs = torch.autograd.grad(loss, [p for _, p in sorted(m.named_parameters())], allow_unused=True)
+    arrays = dict(np_state(m), imgs=imgs.numpy(), labels=labels.numpy(), logits=logits.detach().numpy(),
+                  loss=loss.detach().numpy())
+    for n, gr in zip(names, gs):
+        if gr is not None and gr.numel():
+            arrays["g:" + n] = gr.numpy()
+    meta["vit_small"] = dict(bytes=save("vit_small", **arrays), cfg=cfg, n_params=sum(p.numel() for p in m.parameters()))
+
+
+def gen_vit_moe(mods, meta):
+    cfg = dict(dim=64, image_size=32, patch_size=8, n_heads=2, d_head=64, depth=2, n_experts=4, sel_experts=2,
+               dropout=0.0, num_classes=10)
+    m = mods["vit_moe"].ViTMoE(**cfg)
+    randomize_(m, 71)
+    g = torch.Generator().manual_seed(901)
+    imgs = torch.randn(2, 3, 32, 32, generator=g)
+    labels = torch.tensor([1, 8])
+    logits = m(imgs)
+    loss = F.cross_entropy(logits, labels)
+    names = [n for n, _ in sorted(m.named_parameters())]
+    gs = torch.autograd.grad(loss, [p for _, p in sorted(m.named_parameters())], allow_unused=True)
+    arrays = dict(np_state(m), imgs=imgs.numpy(), labels=labels.numpy(), logits=logits.detach().numpy(),
+                  loss=loss.detach().numpy())
+    for n, gr in zip(names, gs):
+        if gr is not None:
+            arrays["g:" + n] = gr.numpy()
+    meta["vit_moe_small"] = dict(bytes=save("vit_moe_small", **arrays), cfg=cfg,
+                                 n_params=sum(p.numel() for p in m.parameters()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -310,6 +351,8 @@ def main():
     gen_moe(mods, meta)
     gen_switchhead(mods, meta)
     gen_agent(mods, meta)
+    gen_vit(mods, meta)
+    gen_vit_moe(mods, meta)
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     total = sum(v["bytes"] for v in meta.values() if isinstance(v, dict) and "bytes" in v)

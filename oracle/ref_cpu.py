@@ -247,3 +247,52 @@ def vitvqgan_forward(imgs, w, cfg, beta=0.25):
     z = vitvqgan_encode_features(imgs, w, cfg)
     zq, idx, loss = codebook_forward(z, w["codebook.embedding.weight"], beta)
     return vitvqgan_decode_embeds(zq, w, cfg), loss, idx
+
+
+# ------------------------------------------------------------------ ViT / ViTMoE scaffolding
+def _geglu_ffn(x, w):
+    """transformer.FeedForward (models/transformer.py:22-43); inner width may be 0 (ViT quirk)."""
+    hcat = x @ w["ff.0.weight"].t()
+    val, gate = hcat.chunk(2, dim=-1)
+    hid = gate * F.gelu(val)
+    hid = F.layer_norm(hid, hid.shape[-1:], w["ff.2.gamma"], w["ff.2.beta"])
+    return hid @ w["ff.3.weight"].t()
+
+
+def _patch_embed(imgs, w, patch):
+    x = _patchify(imgs, patch)
+    x = _ln(x, w, "to_patch_embedding.1")
+    x = x @ w["to_patch_embedding.2.weight"].t() + w["to_patch_embedding.2.bias"]
+    return _ln(x, w, "to_patch_embedding.3")
+
+
+def vit_forward(imgs, w, patch, n_heads, d_head, depth):
+    """ViT.forward (models/vit.py:52-69) incl. the mult=dropout quirk: the per-layer FFN has the
+    width the checkpoint says (0 at dropout 0.0) and encoder.feed_forward is never applied."""
+    x = _patch_embed(imgs, w, patch)
+    cls = w["class_token"].expand(x.shape[0], 1, -1)
+    x = torch.cat([cls, x], dim=1) + w["pos_enc"]
+    for i in range(depth):
+        lw = _sub(w, f"encoder.layers.{i}")
+        xn = F.layer_norm(x, x.shape[-1:], lw["norm1.gamma"], lw["norm1.beta"])
+        x = softmax_attention(xn, _sub(lw, "self_attn"), n_heads, d_head) + x
+        xn = F.layer_norm(x, x.shape[-1:], lw["norm2.gamma"], lw["norm2.beta"])
+        x = _geglu_ffn(xn, _sub(lw, "feed_forward")) + x
+    return x[:, 0] @ w["final_fc.weight"].t() + w["final_fc.bias"]
+
+
+def vit_moe_forward(imgs, w, patch, n_heads, d_head, depth, n_experts, sel_experts):
+    """ViTMoE.forward (models/vit_moe.py:89-107).  Returns (logits, [per-layer (sel_v, sel_o, sel_moe)])."""
+    x = _patch_embed(imgs, w, patch)
+    cls = w["class_token"].expand(x.shape[0], -1, -1)
+    x = torch.cat([cls, x], dim=1) + w["pos_enc"]
+    sels = []
+    for i in range(depth):
+        lw = _sub(w, f"encoder.layers.{i}")
+        a, sv, so = switchhead_attention(_ln(x, lw, "norm1"), _sub(lw, "self_attn"), n_heads, d_head, n_experts, sel_experts)
+        x = a + x
+        m, sm = moe_layer(_ln(x, lw, "norm2"), _sub(lw, "moe"), n_experts, sel_experts)
+        x = m + x
+        sels.append((sv, so, sm))
+    x = _ln(x, w, "norm")
+    return x[:, 0] @ w["class_embed.weight"].t() + w["class_embed.bias"], sels

@@ -170,3 +170,45 @@ def test_agent_small_matches_reference():
     assert_close(gs[0], fx["gx"], TIGHT, "grad x")
     for n, g in zip(names, gs[1:]):
         assert_close(g, fx["g:" + n], TIGHT, f"grad {n}")
+
+
+def _meta(name):
+    import json
+    import os
+
+    from util import GOLDEN
+
+    return json.load(open(os.path.join(GOLDEN, "golden_meta.json")))[name]
+
+
+def test_vit_small_matches_reference():
+    fx = load_golden("vit_small")
+    cfg = _meta("vit_small")["cfg"]
+    w = {n: v.clone().requires_grad_(v.dtype.is_floating_point) for n, v in weights_of(fx).items()}
+    logits = ref_cpu.vit_forward(torch.from_numpy(fx["imgs"]), w, cfg["patch_size"], cfg["n_heads"], cfg["d_head"], cfg["depth"])
+    assert tuple(logits.shape) == (2, cfg["num_classes"])
+    assert_close(logits, fx["logits"], 1e-5, "logits")
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(fx["labels"]))
+    assert_close(loss, fx["loss"], 1e-5, "loss")
+    names = [n for n in sorted(w) if "g:" + n in fx]
+    gs = torch.autograd.grad(loss, [w[n] for n in names], allow_unused=True)
+    for n, g in zip(names, gs):
+        assert_close(g, fx["g:" + n], 2e-5, f"grad {n}")
+
+
+def test_vit_moe_small_matches_reference():
+    fx = load_golden("vit_moe_small")
+    cfg = _meta("vit_moe_small")["cfg"]
+    w = {n: v.clone().requires_grad_(True) for n, v in weights_of(fx).items()}
+    logits, sels = ref_cpu.vit_moe_forward(torch.from_numpy(fx["imgs"]), w, cfg["patch_size"], cfg["n_heads"], cfg["d_head"],
+                                           cfg["depth"], cfg["n_experts"], cfg["sel_experts"])
+    assert_close(logits, fx["logits"], 1e-5, "logits")
+    loss = torch.nn.functional.cross_entropy(logits, torch.from_numpy(fx["labels"]))
+    assert_close(loss, fx["loss"], 1e-5, "loss")
+    names = sorted(w)
+    gs = torch.autograd.grad(loss, [w[n] for n in names], allow_unused=True)
+    for n, g in zip(names, gs):
+        if "g:" + n in fx:
+            assert_close(g, fx["g:" + n], 5e-5, f"grad {n}")
+        else:
+            assert g is None or float(g.abs().max()) == 0.0, n
