@@ -60,7 +60,8 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_dq_kernel(BwdParams p) {
   const int qi = qb * BLK + wave * 32 + ln;
   const bool qvalid = qi < p.I;
 
-  // B operands held for the whole kernel: (q*scale) and dO of this lane's query.
+  // B operands held for the whole kernel: (q*scale*log2 e) and dO of this lane's query.
+  const float qscale = p.scale * AMK_LOG2E;
   float qreg[32], greg[32];
   float m_q = INFINITY, linv_q = 0.f, delta_q = 0.f;
   {
@@ -70,8 +71,8 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_dq_kernel(BwdParams p) {
     for (int s4 = 0; s4 < 8; ++s4) {
       const float4 t = qvalid ? ld4(qp + 4 * s4) : make_float4(0.f, 0.f, 0.f, 0.f);
       const float4 g = qvalid ? ld4(gp + 4 * s4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      qreg[4 * s4 + 0] = t.x * p.scale; qreg[4 * s4 + 1] = t.y * p.scale;
-      qreg[4 * s4 + 2] = t.z * p.scale; qreg[4 * s4 + 3] = t.w * p.scale;
+      qreg[4 * s4 + 0] = t.x * qscale; qreg[4 * s4 + 1] = t.y * qscale;
+      qreg[4 * s4 + 2] = t.z * qscale; qreg[4 * s4 + 3] = t.w * qscale;
       greg[4 * s4 + 0] = g.x; greg[4 * s4 + 1] = g.y; greg[4 * s4 + 2] = g.z; greg[4 * s4 + 3] = g.w;
     }
     if (qvalid) {
@@ -90,18 +91,12 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_dq_kernel(BwdParams p) {
   const int srow = tid >> 4, scol = (tid & 15) * 4;
   float4 kst[4], vst[4];
   float fillst = 0.f;
+  RowStager kload, vload;
+  kload.init(kbase, p.ks.st, p.J, tid);
+  vload.init(vbase, p.vs.st, p.J, tid);
   auto prefetch = [&](int j0) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int j = j0 + srow + 16 * ps;
-      if (j < p.J) {
-        kst[ps] = ld4(kbase + (int64_t)j * p.ks.st + scol);
-        vst[ps] = ld4(vbase + (int64_t)j * p.vs.st + scol);
-      } else {
-        kst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-        vst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+    kload.load(kst);
+    vload.load(vst);
     if (tid < TILE) {
       const int j = j0 + tid;
       float f = 0.f;
@@ -141,6 +136,7 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_dq_kernel(BwdParams p) {
         }
       }
     }
+    const bool plain = !CAUSAL && kmask == nullptr && (j0 + TILE <= p.J);  // wave-uniform
 
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -159,20 +155,28 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_dq_kernel(BwdParams p) {
         }
       }
       const unsigned cb = u ? cbits1 : cbits0;
+      if (plain) {  // no fills in this tile: dS^T = P^T o (dP^T - delta)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 f = ld4(&Kfill[32 * u + 8 * g + 4 * hf]);
+        for (int r = 0; r < 16; ++r) {
+          const float pr = __builtin_amdgcn_exp2f(s[r] - m_q) * linv_q;
+          s[r] = pr * (dp[r] - delta_q);
+        }
+      } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const float fe = f4(f, e);
-          bool filled = fe != 0.f;
-          float tt = filled ? fe : s[r] * AMK_LOG2E;
-          if (CAUSAL) {
-            if ((cb >> r) & 1u) { tt = AMK_FILL_MASKED; filled = true; }
+        for (int g = 0; g < 4; ++g) {
+          const float4 f = ld4(&Kfill[32 * u + 8 * g + 4 * hf]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const float fe = f4(f, e);
+            bool filled = fe != 0.f;
+            float tt = filled ? fe : s[r];
+            if (CAUSAL) {
+              if ((cb >> r) & 1u) { tt = AMK_FILL_MASKED; filled = true; }
+            }
+            const float pr = __builtin_amdgcn_exp2f(tt - m_q) * linv_q;
+            s[r] = filled ? 0.f : pr * (dp[r] - delta_q);  // dS^T (no gradient through fills)
           }
-          const float pr = __builtin_amdgcn_exp2f(tt - m_q) * linv_q;
-          s[r] = filled ? 0.f : pr * (dp[r] - delta_q);  // dS^T (no gradient through fills)
         }
       }
       // dQ^T += K^T dS^T (32 MFMAs): A = K[key(r,half)][dim], B = dS^T register r
@@ -235,6 +239,7 @@ __global__ __launch_bounds__(WG, CAUSAL ? 1 : 2) void attn_bwd_dkdv_kernel(BwdPa
   float kfill = 0.f;
   if (!kvalid) kfill = -INFINITY;
   else if (p.key_mask && p.key_mask[(int64_t)b * p.J + kj] == 0) kfill = AMK_FILL_MASKED;
+  const bool kfill_wave_plain = __all(kfill == 0.f);
 
   const float* qbase = p.q + (int64_t)b * p.qs.sb + (int64_t)h * p.qs.sh;
   const float* gbase = p.d_o + (int64_t)b * p.dos.sb + (int64_t)h * p.dos.sh;
@@ -244,18 +249,12 @@ __global__ __launch_bounds__(WG, CAUSAL ? 1 : 2) void attn_bwd_dkdv_kernel(BwdPa
   const int srow = tid >> 4, scol = (tid & 15) * 4;
   float4 qst[4], gst[4];
   float mst = 0.f, lst = 0.f, dst = 0.f;
+  RowStager qload, gload;
+  qload.init(qbase, p.qs.st, p.I, tid);
+  gload.init(gbase, p.dos.st, p.I, tid);
   auto prefetch = [&](int i0) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int i = i0 + srow + 16 * ps;
-      if (i < p.I) {
-        qst[ps] = ld4(qbase + (int64_t)i * p.qs.st + scol);
-        gst[ps] = ld4(gbase + (int64_t)i * p.dos.st + scol);
-      } else {
-        qst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-        gst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+    qload.load(qst);
+    gload.load(gst);
     if (tid < TILE) {
       const int i = i0 + tid;
       if (i < p.I) {
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(WG, CAUSAL ? 1 : 2) void attn_bwd_dkdv_kernel(BwdPa
     }
   };
   auto commit = [&]() {
-    const float sc = p.scale;
+    const float sc = p.scale * AMK_LOG2E;  // S comes out in the log2 domain; dK is scaled back by ln 2
 #pragma unroll
     for (int ps = 0; ps < 4; ++ps) {
       const int r = srow + 16 * ps;
@@ -319,6 +318,7 @@ __global__ __launch_bounds__(WG, CAUSAL ? 1 : 2) void attn_bwd_dkdv_kernel(BwdPa
         }
       }
       const unsigned cb = u ? cbits1 : cbits0;
+      const bool plain = !CAUSAL && kfill_wave_plain;  // wave-uniform: none of this wave's keys is filled
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 m4 = ld4(&Ms[32 * u + 8 * g + 4 * hf]);
@@ -327,14 +327,20 @@ __global__ __launch_bounds__(WG, CAUSAL ? 1 : 2) void attn_bwd_dkdv_kernel(BwdPa
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          bool filled = kfill != 0.f;
-          float tt = filled ? kfill : s[r] * AMK_LOG2E;
-          if (CAUSAL) {
-            if ((cb >> r) & 1u) { tt = AMK_FILL_MASKED; filled = true; }
+          if (plain) {
+            const float pr = __builtin_amdgcn_exp2f(s[r] - f4(m4, e)) * f4(l4, e);
+            s[r] = pr;                                   // P
+            dp[r] = pr * (dp[r] - f4(d4, e));            // dS
+          } else {
+            bool filled = kfill != 0.f;
+            float tt = filled ? kfill : s[r];
+            if (CAUSAL) {
+              if ((cb >> r) & 1u) { tt = AMK_FILL_MASKED; filled = true; }
+            }
+            const float pr = __builtin_amdgcn_exp2f(tt - f4(m4, e)) * f4(l4, e);
+            s[r] = pr;                                             // P
+            dp[r] = filled ? 0.f : pr * (dp[r] - f4(d4, e));       // dS
           }
-          const float pr = __builtin_amdgcn_exp2f(tt - f4(m4, e)) * f4(l4, e);
-          s[r] = pr;                                               // P
-          dp[r] = filled ? 0.f : pr * (dp[r] - f4(d4, e));         // dS
         }
       }
       // dV^T += dO^T P ; dK^T += (q*scale)^T dS   (2 x 32 MFMAs)
@@ -355,8 +361,8 @@ __global__ __launch_bounds__(WG, CAUSAL ? 1 : 2) void attn_bwd_dkdv_kernel(BwdPa
     float* dvp = p.dv + (int64_t)b * p.dvs.sb + (int64_t)kj * p.dvs.st + (int64_t)h * p.dvs.sh + 4 * hf;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      st4(dkp + 8 * g, make_float4(dk0[4 * g], dk0[4 * g + 1], dk0[4 * g + 2], dk0[4 * g + 3]));
-      st4(dkp + 32 + 8 * g, make_float4(dk1[4 * g], dk1[4 * g + 1], dk1[4 * g + 2], dk1[4 * g + 3]));
+      st4(dkp + 8 * g, make_float4(dk0[4 * g] * AMK_LN2, dk0[4 * g + 1] * AMK_LN2, dk0[4 * g + 2] * AMK_LN2, dk0[4 * g + 3] * AMK_LN2));
+      st4(dkp + 32 + 8 * g, make_float4(dk1[4 * g] * AMK_LN2, dk1[4 * g + 1] * AMK_LN2, dk1[4 * g + 2] * AMK_LN2, dk1[4 * g + 3] * AMK_LN2));
       st4(dvp + 8 * g, make_float4(dv0[4 * g], dv0[4 * g + 1], dv0[4 * g + 2], dv0[4 * g + 3]));
       st4(dvp + 32 + 8 * g, make_float4(dv1[4 * g], dv1[4 * g + 1], dv1[4 * g + 2], dv1[4 * g + 3]));
     }
@@ -395,6 +401,7 @@ extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, cons
   p.qs = {q_sb, q_st, q_sh}; p.ks = {k_sb, k_st, k_sh}; p.vs = {v_sb, v_st, v_sh}; p.os = {o_sb, o_st, o_sh};
   p.dos = {do_sb, do_st, do_sh}; p.dqs = {dq_sb, dq_st, dq_sh}; p.dks = {dk_sb, dk_st, dk_sh}; p.dvs = {dv_sb, dv_st, dv_sh};
   p.scale = scale;
+  p.pinf = INFINITY;
   p.nqblk = (I + BLK - 1) / BLK;
   p.nkblk = (J + BLK - 1) / BLK;
   AMK_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o) && aligned16(dq) &&
@@ -404,6 +411,9 @@ extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, cons
   const int64_t nrow = (int64_t)B * H * I;
   const int64_t nq = (int64_t)B * H * p.nqblk, nk = (int64_t)B * H * p.nkblk;
   AMK_CHECK_SUPPORTED(nq < (1ll << 31) && nk < (1ll << 31) && (nrow + 15) / 16 < (1ll << 31), "amk_attn_bwd: grid too large");
+  AMK_CHECK_SUPPORTED(((int64_t)J + TILE) * k_st * 4 < (1ll << 31) && ((int64_t)J + TILE) * v_st * 4 < (1ll << 31) &&
+                          ((int64_t)I + TILE) * q_st * 4 < (1ll << 31) && ((int64_t)I + TILE) * do_st * 4 < (1ll << 31),
+                      "amk_attn_bwd: one (batch, head) slab must span < 2 GiB");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (stages & AMK_ATTN_BWD_DELTA)
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, st, p);

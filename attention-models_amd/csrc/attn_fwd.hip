@@ -20,7 +20,7 @@
 
 namespace amk_attn {
 
-template <bool CAUSAL>
+template <bool CAUSAL, bool SCHED>
 __global__ __launch_bounds__(WG, 2) void attn_fwd_kernel(FwdParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE * LDS_STRIDE + TILE];
   float* Ks = smem;
@@ -39,17 +39,19 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_kernel(FwdParams p) {
   const int qi = qb * BLK + wave * 32 + ln;  // this lane's query row
   const bool qvalid = qi < p.I;
 
-  // Q^T operand: lane (query, half) holds (q * scale)[query][32*half + s], s = 0..31.
+  // Q^T operand: lane (query, half) holds (q * scale * log2 e)[query][32*half + s], s = 0..31,
+  // so S^T comes out of the MFMAs already in the log2 domain of the exp2-based softmax.
+  const float qscale = p.scale * AMK_LOG2E;
   float qreg[32];
   {
     const float* qp = p.q + (int64_t)b * p.qs.sb + (int64_t)qi * p.qs.st + (int64_t)h * p.qs.sh + 32 * hf;
 #pragma unroll
     for (int s4 = 0; s4 < 8; ++s4) {
       float4 t = qvalid ? ld4(qp + 4 * s4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      qreg[4 * s4 + 0] = t.x * p.scale;
-      qreg[4 * s4 + 1] = t.y * p.scale;
-      qreg[4 * s4 + 2] = t.z * p.scale;
-      qreg[4 * s4 + 3] = t.w * p.scale;
+      qreg[4 * s4 + 0] = t.x * qscale;
+      qreg[4 * s4 + 1] = t.y * qscale;
+      qreg[4 * s4 + 2] = t.z * qscale;
+      qreg[4 * s4 + 3] = t.w * qscale;
     }
   }
 
@@ -63,18 +65,12 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_kernel(FwdParams p) {
   float4 kst[4], vst[4];
   float fillst = 0.f;
 
+  RowStager kload, vload;
+  kload.init(kbase, p.ks.st, p.J, tid);
+  vload.init(vbase, p.vs.st, p.J, tid);
   auto prefetch = [&](int j0) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int j = j0 + srow + 16 * ps;
-      if (j < p.J) {
-        kst[ps] = ld4(kbase + (int64_t)j * p.ks.st + scol);
-        vst[ps] = ld4(vbase + (int64_t)j * p.vs.st + scol);
-      } else {
-        kst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-        vst[ps] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    }
+    kload.load(kst);
+    vload.load(vst);
     if (tid < TILE) {
       const int j = j0 + tid;
       float f = 0.f;
@@ -119,73 +115,116 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_kernel(FwdParams p) {
     }
 
     // ---- S^T = K Q^T for the two 32-key halves of the tile (2 x 32 MFMAs) ----
+    // K fragments are read one 4-deep k-block AHEAD of the MFMAs that consume them, so an
+    // LDS round trip never sits between two MFMAs of this wave.
     f32x16 s0 = zero16(), s1 = zero16();
     {
       const float* k0 = &Ks[ln * LDS_STRIDE + 32 * hf];
       const float* k1 = &Ks[(32 + ln) * LDS_STRIDE + 32 * hf];
+      float4 a0 = ld4(k0), a1 = ld4(k1);
+      if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the prologue reads
 #pragma unroll
       for (int s4 = 0; s4 < 8; ++s4) {
-        const float4 a0 = ld4(k0 + 4 * s4);
-        const float4 a1 = ld4(k1 + 4 * s4);
+        float4 n0 = a0, n1 = a1;
+        if (s4 + 1 < 8) {
+          n0 = ld4(k0 + 4 * (s4 + 1));
+          n1 = ld4(k1 + 4 * (s4 + 1));
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           s0 = mfma32(f4(a0, e), qreg[4 * s4 + e], s0);
           s1 = mfma32(f4(a1, e), qreg[4 * s4 + e], s1);
         }
-      }
-    }
-
-    // ---- fills, log2 scaling, online softmax (lane-local + one cross-half exchange) ----
-    float mx = -INFINITY;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 f0 = ld4(&Kfill[8 * g + 4 * hf]);
-      const float4 f1 = ld4(&Kfill[32 + 8 * g + 4 * hf]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        float t0 = s0[r] * AMK_LOG2E, t1 = s1[r] * AMK_LOG2E;
-        const float fa = f4(f0, e), fb = f4(f1, e);
-        t0 = (fa == 0.f) ? t0 : fa;
-        t1 = (fb == 0.f) ? t1 : fb;
-        if (CAUSAL) {
-          t0 = ((cbits0 >> r) & 1u) ? AMK_FILL_MASKED : t0;
-          t1 = ((cbits1 >> r) & 1u) ? AMK_FILL_MASKED : t1;
+        if (SCHED) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the 2 reads of the next k-block
+          __builtin_amdgcn_sched_group_barrier(0x008, 8, 0);  // then this block's 8 MFMAs
         }
-        s0[r] = t0;
-        s1[r] = t1;
-        mx = fmaxf(mx, fmaxf(t0, t1));
+        a0 = n0;
+        a1 = n1;
       }
     }
-    mx = wave_xor32_max(mx);
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float lsum = 0.f;
+    // ---- fills and online softmax (lane-local + one cross-half exchange) ----
+    // "plain" tiles (no key mask, no causal mask, all 64 keys inside the sequence) skip the fills.
+    const bool plain = !CAUSAL && kmask == nullptr && (j0 + TILE <= p.J);  // wave-uniform
+    float mx;
+    if (plain) {
+      mx = vmax(s0[0], s1[0], p.pinf);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = vmax(mx, vmax(s0[r], s1[r], p.pinf), p.pinf);
+    } else {
+      mx = -INFINITY;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 f0 = ld4(&Kfill[8 * g + 4 * hf]);
+        const float4 f1 = ld4(&Kfill[32 + 8 * g + 4 * hf]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          float t0 = s0[r], t1 = s1[r];
+          const float fa = f4(f0, e), fb = f4(f1, e);
+          t0 = (fa == 0.f) ? t0 : fa;
+          t1 = (fb == 0.f) ? t1 : fb;
+          if (CAUSAL) {
+            t0 = ((cbits0 >> r) & 1u) ? AMK_FILL_MASKED : t0;
+            t1 = ((cbits1 >> r) & 1u) ? AMK_FILL_MASKED : t1;
+          }
+          s0[r] = t0;
+          s1[r] = t1;
+          mx = vmax(mx, vmax(t0, t1, p.pinf), p.pinf);
+        }
+      }
+    }
+    mx = vmax(mx, __shfl_xor(mx, 32, 64), p.pinf);
+    const float m_new = vmax(m_run, mx, p.pinf);
+    f32x2 lsum2 = {0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float p0 = __builtin_amdgcn_exp2f(s0[r] - m_new);
       const float p1 = __builtin_amdgcn_exp2f(s1[r] - m_new);
       s0[r] = p0;
       s1[r] = p1;
-      lsum += p0 + p1;
+      lsum2 += (f32x2){p0, p1};  // one v_pk_add_f32 per pair
     }
-    l_run = l_run * alpha + lsum;
-    m_run = m_new;
+    const float lsum = lsum2.x + lsum2.y;
+    if (__any(m_new != m_run)) {  // the running max moved for some row of this wave: rescale
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      o0[r] *= alpha;
-      o1[r] *= alpha;
+      for (int r = 0; r < 16; ++r) {
+        o0[r] *= alpha;
+        o1[r] *= alpha;
+      }
+      m_run = m_new;
     }
+    l_run += lsum;
 
     // ---- O^T += V^T P^T (2 x 32 MFMAs); P^T is the S^T accumulator as it stands ----
+    // V fragments are read one step (4 MFMAs) ahead.
+    {
+      const float* vcol = &Vs[(4 * hf) * LDS_STRIDE + ln];
+      // step r uses rows acc_row(r, hf) and 32 + acc_row(r, hf), columns ln and ln + 32
+      float c0 = vcol[0], c1 = vcol[32], c2 = vcol[32 * LDS_STRIDE], c3 = vcol[32 * LDS_STRIDE + 32];
+      if (SCHED) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the prologue reads
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float* v0 = &Vs[acc_row(r, hf) * LDS_STRIDE + ln];
-      const float* v1 = &Vs[(32 + acc_row(r, hf)) * LDS_STRIDE + ln];
-      o0 = mfma32(v0[0], s0[r], o0);
-      o1 = mfma32(v0[32], s0[r], o1);
-      o0 = mfma32(v1[0], s1[r], o0);
-      o1 = mfma32(v1[32], s1[r], o1);
+      for (int r = 0; r < 16; ++r) {
+        float n0 = c0, n1 = c1, n2 = c2, n3 = c3;
+        if (r + 1 < 16) {
+          const int row = ((r + 1) & 3) + 8 * ((r + 1) >> 2);
+          n0 = vcol[row * LDS_STRIDE];
+          n1 = vcol[row * LDS_STRIDE + 32];
+          n2 = vcol[(32 + row) * LDS_STRIDE];
+          n3 = vcol[(32 + row) * LDS_STRIDE + 32];
+        }
+        o0 = mfma32(c0, s0[r], o0);
+        o1 = mfma32(c1, s0[r], o1);
+        o0 = mfma32(c2, s1[r], o0);
+        o1 = mfma32(c3, s1[r], o1);
+        if (SCHED) {
+          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+        }
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      }
     }
   }
 
@@ -231,17 +270,20 @@ extern "C" int amk_attn_fwd(const float* q, const float* k, const float* v, floa
   p.B = B; p.H = H; p.I = I; p.J = J;
   p.qs = {q_sb, q_st, q_sh}; p.ks = {k_sb, k_st, k_sh}; p.vs = {v_sb, v_st, v_sh}; p.os = {o_sb, o_st, o_sh};
   p.scale = scale;
+  p.pinf = INFINITY;
   p.nblk = (I + BLK - 1) / BLK;
   AMK_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && strides_ok(p.qs) &&
                     strides_ok(p.ks) && strides_ok(p.vs) && strides_ok(p.os),
                 "amk_attn_fwd: pointers must be 16-byte aligned and strides multiples of 4 elements");
   const int64_t nwg = (int64_t)B * H * p.nblk;
   AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_fwd: grid too large");
+  AMK_CHECK_SUPPORTED(((int64_t)J + TILE) * k_st * 4 < (1ll << 31) && ((int64_t)J + TILE) * v_st * 4 < (1ll << 31),
+                      "amk_attn_fwd: one (batch, head) K/V slab must span < 2 GiB");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (causal_mask)
-    hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3((unsigned)nwg), dim3(WG), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   else
-    hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3((unsigned)nwg), dim3(WG), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   AMK_CHECK_LAUNCH("amk_attn_fwd");
   return AMK_OK;
 }

@@ -130,11 +130,15 @@ def main():
     from amk.train import VQGANTrainStep
 
     lib.load()
+    # let MIOpen time its convolution algorithms once (the PatchGAN discriminator; plumbing, not hot path)
+    torch.backends.cudnn.benchmark = os.environ.get("AMK_MIOPEN_FIND", "1") == "1"
     torch.manual_seed(0)  # identical init on every rank (and broadcast from rank 0 anyway)
     model = ViTVQGAN(VIT, CODEBOOK)
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev)
     discr = NLayerDiscriminator(3, 64, 3).to(dev)
+    if os.environ.get("AMK_DISCR_NHWC", "0") == "1":
+        discr = discr.to(memory_format=torch.channels_last)
     trainer = VQGANTrainStep(model, discr)
     g = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, VIT["img_size"], VIT["img_size"], generator=g).to(dev)
@@ -201,10 +205,16 @@ def main():
         }
         if kernels:
             dom = max(kernels[:3], key=lambda r: r["ms_per_step"])
+            traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same batch)
+            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_kernels_b32.json")
+            if os.path.exists(pmc_path):
+                pmc = json.load(open(pmc_path))
+                if pmc.get("batch") == args.batch and dom["kernel"] in pmc["kernels"]:
+                    traffic = pmc["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
             line["roofline"] = {
                 "kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac_of_f32_mfma_peak"],
-                "traffic": None, "avg_launch_ms": dom["avg_ms"], "flop_per_launch": dom["flop"],
+                "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "flop_per_launch": dom["flop"],
             }
             line["kernels"] = kernels
         if cpu:
