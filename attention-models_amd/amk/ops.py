@@ -91,7 +91,15 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale):
     return q, k, v, o, stats
 
 
-def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, scale, stages=7, delta=None):
+# Backward path of the attention core: False (default) = one fused pass, each product computed once,
+# dq accumulated with f32 atomics (last-bit run-to-run differences in dq); True = two recompute
+# kernels, no atomics, bitwise reproducible (include/amk.h, amk_attn_bwd `stages`).
+DETERMINISTIC_ATTENTION_BACKWARD = False
+
+
+def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, scale, stages=None, delta=None):
+    if stages is None:
+        stages = 7 if DETERMINISTIC_ATTENTION_BACKWARD else 9
     B, H, I, D = q.shape
     J = k.shape[2]
     d_o = _as_kernel_view(d_o)

@@ -417,6 +417,11 @@ extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, cons
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (stages & AMK_ATTN_BWD_DELTA)
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, st, p);
+  if (stages & AMK_ATTN_BWD_FUSED) {
+    // one-pass kernel when the layout / masks allow it, else the two recompute kernels
+    if (launch_attn_bwd_fused(p, st)) stages &= ~(AMK_ATTN_BWD_DKDV | AMK_ATTN_BWD_DQ);
+    else stages |= AMK_ATTN_BWD_DKDV | AMK_ATTN_BWD_DQ;
+  }
   if (stages & AMK_ATTN_BWD_DKDV) {
     if (causal_mask) hipLaunchKernelGGL(attn_bwd_dkdv_kernel<true>, dim3((unsigned)nk), dim3(WG), 0, st, p);
     else hipLaunchKernelGGL(attn_bwd_dkdv_kernel<false>, dim3((unsigned)nk), dim3(WG), 0, st, p);

@@ -59,26 +59,28 @@ __device__ __forceinline__ f32x16 zero16() {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Streams TILE rows x 64 floats of one (batch, head) operand, global -> registers, 4 x 16 B per
+// Streams ROWS rows x 64 floats of one (batch, head) operand, global -> registers, 4 x 16 B per
 // thread (row = tid/16 + 16*pass, 16 B at column 4*(tid%16)), through a raw buffer descriptor:
 // the hardware range check returns zeros for rows beyond the sequence, so a tile costs four
 // address adds and no compares / selects / 64-bit multiplies (every VALU instruction is paid
 // at ~4 cycles against the f32 MFMA pipe: tools/ubench_mfma_valu.hip).
-struct RowStager {
+template <int ROWS>
+struct RowStagerT {
+  static constexpr int NP = ROWS / 16;
   __amdgpu_buffer_rsrc_t rsrc;
-  int voff[4];
+  int voff[NP];
   int step;
   __device__ __forceinline__ void init(const float* base, int64_t row_stride, int nrows, int tid) {
     // bytes up to the end of the last row's 64-float slice; base / size are wave-uniform
     rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((int64_t)(nrows - 1) * row_stride + 64) * 4), 0x00020000);
     const int srow = tid >> 4, scol = (tid & 15) * 4;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) voff[ps] = (int)(((int64_t)(srow + 16 * ps) * row_stride + scol) * 4);
-    step = (int)(TILE * row_stride * 4);
+    for (int ps = 0; ps < NP; ++ps) voff[ps] = (int)(((int64_t)(srow + 16 * ps) * row_stride + scol) * 4);
+    step = (int)(ROWS * row_stride * 4);
   }
-  __device__ __forceinline__ void load(float4 (&dst)[4]) {
+  __device__ __forceinline__ void load(float4 (&dst)[NP]) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
+    for (int ps = 0; ps < NP; ++ps) {
       // the builtin returns one 128-bit value: bit_cast it (assigning it to a 4 x u32 vector
       // would splat its low dword)
       dst[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff[ps], 0, 0));
@@ -86,11 +88,15 @@ struct RowStager {
     }
   }
 };
+typedef RowStagerT<TILE> RowStager;
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float f4(const float4& v, int e) {
   return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
 }
+
+// attn_bwd_fused.hip: one-pass backward (dQ by atomics); false = not applicable, nothing launched.
+bool launch_attn_bwd_fused(const BwdParams& p, hipStream_t st);
 
 }  // namespace amk_attn

@@ -78,13 +78,18 @@ int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float
  * as o with its own strides).  Outputs: dq (q-like), dk (k-like), dv (v-like),
  * each fully overwritten.  delta_ws: workspace of B*H*I floats.
  * Gradients do not flow through filled (-1e9) positions, as in masked_fill.
- * `stages` selects the launches (bit 0: delta = rowsum(dO*O) into delta_ws, bit 1: dK/dV,
- * bit 2: dQ); pass AMK_ATTN_BWD_ALL.  Profilers time one stage by passing its bit alone
- * (bits 1 and 2 read delta_ws, so bit 0 must have run before). */
+ * `stages` selects the launches.  bit 0: delta = rowsum(dO*O) into delta_ws (must have run
+ * before any other bit).  Then EITHER bit 3 (AMK_ATTN_BWD_FUSED): one pass, each of the five
+ * products computed once, dq accumulated with f32 atomics (dq must be the dense (B,I,H,D) layout;
+ * it is zeroed here; dq differs in the last bits from run to run; falls back to the two-kernel
+ * path when a causal mask is given or dq is strided) -- OR bits 1 and 2: two recompute kernels,
+ * dK/dV and dQ, no atomics, bitwise reproducible.  Profilers time one stage by passing its bit. */
 #define AMK_ATTN_BWD_DELTA 1
 #define AMK_ATTN_BWD_DKDV 2
 #define AMK_ATTN_BWD_DQ 4
-#define AMK_ATTN_BWD_ALL 7
+#define AMK_ATTN_BWD_FUSED 8
+#define AMK_ATTN_BWD_ALL 7          /* delta + dK/dV + dQ: reproducible */
+#define AMK_ATTN_BWD_FAST 9         /* delta + fused */
 int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  const float* stats, const float* d_o,
                  float* dq, float* dk, float* dv, float* delta_ws,

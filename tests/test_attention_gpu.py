@@ -14,6 +14,17 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
+@pytest.fixture(params=["fused", "deterministic"], autouse=True)
+def backward_path(request):
+    """Every test runs with both backward paths of the attention core (amk_attn_bwd `stages`)."""
+    from amk import ops
+
+    old = ops.DETERMINISTIC_ATTENTION_BACKWARD
+    ops.DETERMINISTIC_ATTENTION_BACKWARD = request.param == "deterministic"
+    yield request.param
+    ops.DETERMINISTIC_ATTENTION_BACKWARD = old
+
+
 def _core_case(device, B, H, I, J, key_mask=None, causal=None, seed=0, layout="bthd"):
     from amk import ops
 
@@ -180,6 +191,15 @@ def test_full_size_properties(device):
     ab = ops.attention(q, k, v1 + 2 * v2, s)
     assert_close(ab, a + 2 * b, 1e-5, "linearity in v")
     assert torch.equal(a, ops.attention(q, k, v1, s))
+    # backward determinism: the two-kernel path is bitwise reproducible; the fused path is in dk, dv
+    qg, kg, vg = (t.clone().requires_grad_(True) for t in (q, k, v1))
+    g1 = torch.autograd.grad(ops.attention(qg, kg, vg, s).square().sum(), [qg, kg, vg])
+    g2 = torch.autograd.grad(ops.attention(qg, kg, vg, s).square().sum(), [qg, kg, vg])
+    assert torch.equal(g1[1], g2[1]) and torch.equal(g1[2], g2[2])
+    if ops.DETERMINISTIC_ATTENTION_BACKWARD:
+        assert torch.equal(g1[0], g2[0])
+    else:
+        assert_close(g1[0], g2[0], 1e-5, "dq run-to-run")
     # one (batch, head) slice against the oracle
     o_ref = ref_cpu.attention_core(q[3:4, 5:6].cpu(), k[3:4, 5:6].cpu(), v1[3:4, 5:6].cpu(), s)
     assert_close(a[3:4, 5:6], o_ref, TOL, "slice vs oracle")
