@@ -133,15 +133,16 @@ def main():
     from amk.train import VQGANTrainStep
 
     lib.load()
-    # let MIOpen time its convolution algorithms once (the PatchGAN discriminator; plumbing, not hot path)
-    torch.backends.cudnn.benchmark = os.environ.get("AMK_MIOPEN_FIND", "1") == "1"
+    # vendor-library kernel selection for the non-hot-path GEMMs / convolutions (amk/tuning)
+    from amk import tuning
+    tuning.enable_conv_autotune(os.environ.get("AMK_MIOPEN_FIND", "1") == "1")
+    if os.environ.get("AMK_TUNABLEOP", "1") == "1":
+        tuning.enable_gemm_tuning()
     torch.manual_seed(0)  # identical init on every rank (and broadcast from rank 0 anyway)
     model = ViTVQGAN(VIT, CODEBOOK)
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev)
     discr = NLayerDiscriminator(3, 64, 3).to(dev)
-    if os.environ.get("AMK_DISCR_NHWC", "0") == "1":
-        discr = discr.to(memory_format=torch.channels_last)
     trainer = VQGANTrainStep(model, discr)
     g = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, VIT["img_size"], VIT["img_size"], generator=g).to(dev)
