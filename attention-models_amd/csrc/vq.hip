@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
   };
 
   float best = INFINITY;
-  int bidx = kbeg;
+  int bbase = kbeg, bsub = 0;
   prefetch(0);
   for (int t = 0; t < ntile; ++t) {
     __syncthreads();
@@ -156,6 +156,10 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(f4(a, e), zreg[4 * s4 + e], acc);
       }
+      // Running (min, argmin).  Every VALU instruction is paid against the f32 MFMA pipe, so the
+      // index is kept as (sub-tile base, register number): the per-element select then takes the
+      // register number as an inline constant, and the base moves once per sub-tile.
+      const float before = best;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 e4 = ld4(&EEs[32 * u + 8 * g + 4 * hf]);
@@ -164,14 +168,16 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
           const int r = 4 * g + e;
           // (sum z^2 + sum e^2) - 2*dot : same association as the reference expression
           const float d = __builtin_fmaf(-2.f, acc[r], zz + f4(e4, e));
-          const int code = c0 + 32 * u + 8 * g + 4 * hf + e;
           const bool lt = d < best;  // strict: the first minimum wins, codes ascend per lane
           best = lt ? d : best;
-          bidx = lt ? code : bidx;
+          bsub = lt ? r : bsub;
         }
       }
+      bbase = (best != before) ? (c0 + 32 * u) : bbase;
     }
   }
+  // code = sub-tile base + row of accumulator register bsub for this half-wave
+  int bidx = bbase + (bsub & 3) + 8 * (bsub >> 2) + 4 * hf;
   // merge the two half-waves of a row (they own interleaved codes): lowest index on ties
   const float ob = __shfl_xor(best, 32, 64);
   const int oi = __shfl_xor(bidx, 32, 64);
