@@ -122,10 +122,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run (see docstring)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no HIP device is visible (there is no CPU path)")
+    # rehearsal switch for a 1-GPU box: AMK_REHEARSE_SHARED_GPU=1 puts every rank on cuda:0 over gloo
+    # (RCCL refuses two ranks on one device); the timed numbers of such a run mean nothing.
+    rehearse = os.environ.get("AMK_REHEARSE_SHARED_GPU", "0") == "1"
+    if rehearse:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from amk import lib
     from amk.models import ViTVQGAN
