@@ -18,8 +18,8 @@
 //   combine        : out[g]  = sum_outer ( sum_{slots, ascending expert id} s[p] * Y[p] )
 //   gate_grad      : dlogit[u, ids[p]] = sigmoid'(.) * <dOut[p/g_div], Y[p]>
 //
-// A "pair" p = unit*k + slot.  Tiles are 64 pairs x 64 outputs x 32 deep, 4 waves, one 32x32
-// accumulator per wave with the OUTPUT FEATURE ON THE LANE (coalesced 128-B row segments on
+// A "pair" p = unit*k + slot.  Tiles are 64 pairs x 64 (or 128) outputs x 32 deep, 4 waves, one (or
+// two) 32x32 accumulators per wave with the OUTPUT FEATURE ON THE LANE (coalesced 128-B row segments on
 // store, per-lane bias), operands through LDS with row stride 36 / 68 floats (conflict-free
 // ds_read_b128 row reads, ds_read_b32 column reads).
 #include "amk_common.h"
@@ -122,44 +122,55 @@ __device__ __forceinline__ bool find_tile(const int32_t* offsets, int E, int til
   return false;
 }
 
-// Y[p, n] = sum_kk A[arow(p), kk] * W[e, n, kk] (+ bias[e, n])
+// All three GEMM kernels are templated on NB: every wave keeps NB 32x32 accumulators that share one
+// operand fragment (NB = 2 halves the LDS reads, barriers and staging per MFMA; NB = 1 serves the
+// 64-wide outputs of SwitchHead's V experts).
+
+// Y[p, n] = sum_kk A[arow(p), kk] * W[e, n, kk] (+ bias[e, n])        tile: 64 pairs x 64*NB outputs
+template <int NB>
 __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
-  constexpr int LS = 36;
-  __shared__ __attribute__((aligned(16))) float smem[2 * 64 * LS];
+  constexpr int LS = 36, BN = 64 * NB;
+  __shared__ __attribute__((aligned(16))) float smem[(64 + BN) * LS];
   __shared__ int prow[64];
   float* As = smem;
   float* Ws = smem + 64 * LS;
   int e, m0, cnt;
   if (!find_tile(g.offsets, g.E, blockIdx.x, e, m0, cnt)) return;
-  const int n0 = blockIdx.y * 64;
+  const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
   __syncthreads();
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
 
-  // staging: 64 rows x 32 floats = 512 float4 per operand, 2 per thread
-  const int sr = tid >> 3, sc = (tid & 7) * 4;  // rows sr, sr+32
-  const int pa = prow[sr], pb = prow[sr + 32];
-  const float* arow0 = pa >= 0 ? g.A + (int64_t)(pa / g.a_div) * g.lda : nullptr;
-  const float* arow1 = pb >= 0 ? g.A + (int64_t)(pb / g.a_div) * g.lda : nullptr;
-  const float* wrow0 = (n0 + sr < g.N) ? We + (int64_t)(n0 + sr) * g.Kd : nullptr;
-  const float* wrow1 = (n0 + sr + 32 < g.N) ? We + (int64_t)(n0 + sr + 32) * g.Kd : nullptr;
-  float4 a0, a1, w0, w1;
+  // staging: rows sr + 32*j, 4 floats at column sc
+  const int sr = tid >> 3, sc = (tid & 7) * 4;
+  const float* arow[2];
+  const float* wrow[2 * NB];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pp = prow[sr + 32 * j];
+    arow[j] = pp >= 0 ? g.A + (int64_t)(pp / g.a_div) * g.lda : nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < 2 * NB; ++j) wrow[j] = (n0 + sr + 32 * j < g.N) ? We + (int64_t)(n0 + sr + 32 * j) * g.Kd : nullptr;
+  float4 ast[2], wst[2 * NB];
   auto prefetch = [&](int k0) {
     const bool kin = k0 + sc < g.Kd;
-    a0 = (arow0 && kin) ? ld4(arow0 + k0 + sc) : zero4();
-    a1 = (arow1 && kin) ? ld4(arow1 + k0 + sc) : zero4();
-    w0 = (wrow0 && kin) ? ld4(wrow0 + k0 + sc) : zero4();
-    w1 = (wrow1 && kin) ? ld4(wrow1 + k0 + sc) : zero4();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ast[j] = (arow[j] && kin) ? ld4(arow[j] + k0 + sc) : zero4();
+#pragma unroll
+    for (int j = 0; j < 2 * NB; ++j) wst[j] = (wrow[j] && kin) ? ld4(wrow[j] + k0 + sc) : zero4();
   };
   auto commit = [&]() {
-    st4(&As[sr * LS + sc], a0);
-    st4(&As[(sr + 32) * LS + sc], a1);
-    st4(&Ws[sr * LS + sc], w0);
-    st4(&Ws[(sr + 32) * LS + sc], w1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) st4(&As[(sr + 32 * j) * LS + sc], ast[j]);
+#pragma unroll
+    for (int j = 0; j < 2 * NB; ++j) st4(&Ws[(sr + 32 * j) * LS + sc], wst[j]);
   };
-  f32x16 acc = zero16();
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) acc[j] = zero16();
   prefetch(0);
   for (int k0 = 0; k0 < g.Kd; k0 += 32) {
     __syncthreads();
@@ -167,63 +178,80 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
     __syncthreads();
     if (k0 + 32 < g.Kd) prefetch(k0 + 32);
     const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
-    const float* wr = &Ws[(32 * wn + ln) * LS + 16 * hf];
+    const float* wr = &Ws[(32 * NB * wn + ln) * LS + 16 * hf];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const float4 a = ld4(ar + 4 * s4);
-      const float4 b = ld4(wr + 4 * s4);
+      float4 b[NB];
 #pragma unroll
-      for (int x = 0; x < 4; ++x) acc = mfma32(f4(a, x), f4(b, x), acc);
+      for (int j = 0; j < NB; ++j) b[j] = ld4(wr + 32 * j * LS + 4 * s4);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = mfma32(f4(a, x), f4(b[j], x), acc[j]);
+      }
     }
   }
-  const int n = n0 + 32 * wn + ln;
-  if (n < g.N) {
-    const float bv = g.bias ? g.bias[(int64_t)e * g.N + n] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int p = prow[32 * wm + acc_row(r, hf)];
-      if (p >= 0) g.Y[(int64_t)p * g.N + n] = acc[r] + bv;
+  for (int j = 0; j < NB; ++j) {
+    const int n = n0 + 32 * NB * wn + 32 * j + ln;
+    if (n < g.N) {
+      const float bv = g.bias ? g.bias[(int64_t)e * g.N + n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = prow[32 * wm + acc_row(r, hf)];
+        if (p >= 0) g.Y[(int64_t)p * g.N + n] = acc[j][r] + bv;
+      }
     }
   }
 }
 
-// Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk]
+// Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk]              tile: 64 pairs x 64*NB outputs
+template <int NB>
 __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
-  constexpr int LS = 36, WS = 68;
+  constexpr int LS = 36, BC = 64 * NB, WS = BC + 4;
   __shared__ __attribute__((aligned(16))) float smem[64 * LS + 32 * WS];
   __shared__ int prow[64];
   float* As = smem;            // [64 pairs][32 n]
-  float* Ws = smem + 64 * LS;  // [32 n][64 kk]
+  float* Ws = smem + 64 * LS;  // [32 n][BC kk]
   int e, m0, cnt;
   if (!find_tile(g.offsets, g.E, blockIdx.x, e, m0, cnt)) return;
-  const int c0 = blockIdx.y * 64;  // output (kk) tile
+  const int c0 = blockIdx.y * BC;  // output (kk) tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
   __syncthreads();
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
 
-  const int sr = tid >> 3, sc = (tid & 7) * 4;    // A: rows sr, sr+32; cols sc
-  const int wr_ = tid >> 4, wc = (tid & 15) * 4;  // W: rows wr_, wr_+16 (n); cols wc (kk)
-  const int pa = prow[sr], pb = prow[sr + 32];
-  const float* arow0 = pa >= 0 ? g.A + (int64_t)(pa / g.a_div) * g.lda : nullptr;
-  const float* arow1 = pb >= 0 ? g.A + (int64_t)(pb / g.a_div) * g.lda : nullptr;
+  const int sr = tid >> 3, sc = (tid & 7) * 4;      // A: rows sr, sr+32; cols sc
+  constexpr int TPR = BC / 4;                        // threads per W row (16 B each)
+  constexpr int RPP = 256 / TPR;                     // W rows per pass
+  const int wrow_ = tid / TPR, wc = (tid % TPR) * 4; // W: rows wrow_ + RPP*j (n); cols wc (kk)
+  const float* arow[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int pp = prow[sr + 32 * j];
+    arow[j] = pp >= 0 ? g.A + (int64_t)(pp / g.a_div) * g.lda : nullptr;
+  }
   const bool cin = c0 + wc < g.Kd;
-  float4 a0, a1, w0, w1;
+  float4 ast[2], wst[32 / RPP];
   auto prefetch = [&](int nb) {
     const bool nin = nb + sc < g.N;
-    a0 = (arow0 && nin) ? ld4(arow0 + nb + sc) : zero4();
-    a1 = (arow1 && nin) ? ld4(arow1 + nb + sc) : zero4();
-    w0 = (cin && nb + wr_ < g.N) ? ld4(We + (int64_t)(nb + wr_) * g.Kd + c0 + wc) : zero4();
-    w1 = (cin && nb + wr_ + 16 < g.N) ? ld4(We + (int64_t)(nb + wr_ + 16) * g.Kd + c0 + wc) : zero4();
+#pragma unroll
+    for (int j = 0; j < 2; ++j) ast[j] = (arow[j] && nin) ? ld4(arow[j] + nb + sc) : zero4();
+#pragma unroll
+    for (int j = 0; j < 32 / RPP; ++j)
+      wst[j] = (cin && nb + wrow_ + RPP * j < g.N) ? ld4(We + (int64_t)(nb + wrow_ + RPP * j) * g.Kd + c0 + wc) : zero4();
   };
   auto commit = [&]() {
-    st4(&As[sr * LS + sc], a0);
-    st4(&As[(sr + 32) * LS + sc], a1);
-    st4(&Ws[wr_ * WS + wc], w0);
-    st4(&Ws[(wr_ + 16) * WS + wc], w1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) st4(&As[(sr + 32 * j) * LS + sc], ast[j]);
+#pragma unroll
+    for (int j = 0; j < 32 / RPP; ++j) st4(&Ws[(wrow_ + RPP * j) * WS + wc], wst[j]);
   };
-  f32x16 acc = zero16();
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) acc[j] = zero16();
   prefetch(0);
   for (int nb = 0; nb < g.N; nb += 32) {
     __syncthreads();
@@ -231,60 +259,79 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
     __syncthreads();
     if (nb + 32 < g.N) prefetch(nb + 32);
     const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
-    const float* wc_ = &Ws[(16 * hf) * WS + 32 * wn + ln];
+    const float* wc_ = &Ws[(16 * hf) * WS + 32 * NB * wn + ln];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
       const float4 a = ld4(ar + 4 * s4);
 #pragma unroll
-      for (int x = 0; x < 4; ++x) acc = mfma32(f4(a, x), wc_[(4 * s4 + x) * WS], acc);
+      for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = mfma32(f4(a, x), wc_[(4 * s4 + x) * WS + 32 * j], acc[j]);
+      }
     }
   }
-  const int c = c0 + 32 * wn + ln;
-  if (c < g.Kd) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int p = prow[32 * wm + acc_row(r, hf)];
-      if (p >= 0) g.Y[(int64_t)p * g.Kd + c] = acc[r] * (g.scale ? g.scale[p] : 1.f);
+  for (int j = 0; j < NB; ++j) {
+    const int c = c0 + 32 * NB * wn + 32 * j + ln;
+    if (c < g.Kd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = prow[32 * wm + acc_row(r, hf)];
+        if (p >= 0) g.Y[(int64_t)p * g.Kd + c] = acc[j][r] * (g.scale ? g.scale[p] : 1.f);
+      }
     }
   }
 }
 
 // dW[e, n, kk] = sum_{p in e} scale[p] * G[p/a_div, n] * X[p/b_div, kk] ; dbias[e, n] = sum_p scale[p] * G[.., n]
+// tile: 64 n x 64*NB kk
+template <int NB>
 __global__ __launch_bounds__(256, 2) void grouped_wgrad_kernel(GemmParams g) {
-  constexpr int WS = 68;
-  __shared__ __attribute__((aligned(16))) float smem[2 * 32 * WS];
+  constexpr int GS = 68, BC = 64 * NB, XS = BC + 4;
+  __shared__ __attribute__((aligned(16))) float smem[32 * GS + 32 * XS];
   float* Gs = smem;            // [32 pairs][64 n]   (already scaled)
-  float* Xs = smem + 32 * WS;  // [32 pairs][64 kk]
+  float* Xs = smem + 32 * GS;  // [32 pairs][BC kk]
   const int e = blockIdx.z;
-  const int n0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64, c0 = blockIdx.x * BC;
   const int beg = g.offsets[e], cnt = g.offsets[e + 1] - beg;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;  // wm: n half, wn: kk half
-  const int sr = tid >> 4, sc = (tid & 15) * 4;  // rows sr, sr+16 (pairs); cols sc
-  float4 g0, g1, x0, x1;
+  const int sr = tid >> 4, sc = (tid & 15) * 4;  // G: rows sr, sr+16 (pairs); cols sc
+  constexpr int TPR = BC / 4, RPP = 256 / TPR;
+  const int xr = tid / TPR, xc = (tid % TPR) * 4;  // X: rows xr + RPP*j
+  float4 gst[2], xst[32 / RPP];
   auto prefetch = [&](int m) {
-    const int ia = m + sr, ib = m + sr + 16;
-    g0 = g1 = x0 = x1 = zero4();
-    if (ia < cnt) {
-      const int p = g.perm[beg + ia];
-      const float s = g.scale ? g.scale[p] : 1.f;
-      if (n0 + sc < g.N) { g0 = ld4(g.A + (int64_t)(p / g.a_div) * g.lda + n0 + sc); g0.x *= s; g0.y *= s; g0.z *= s; g0.w *= s; }
-      if (c0 + sc < g.Kd) x0 = ld4(g.B2 + (int64_t)(p / g.b_div) * g.ldb + c0 + sc);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      gst[j] = zero4();
+      const int i = m + sr + 16 * j;
+      if (i < cnt && n0 + sc < g.N) {
+        const int p = g.perm[beg + i];
+        const float s = g.scale ? g.scale[p] : 1.f;
+        float4 t = ld4(g.A + (int64_t)(p / g.a_div) * g.lda + n0 + sc);
+        t.x *= s; t.y *= s; t.z *= s; t.w *= s;
+        gst[j] = t;
+      }
     }
-    if (ib < cnt) {
-      const int p = g.perm[beg + ib];
-      const float s = g.scale ? g.scale[p] : 1.f;
-      if (n0 + sc < g.N) { g1 = ld4(g.A + (int64_t)(p / g.a_div) * g.lda + n0 + sc); g1.x *= s; g1.y *= s; g1.z *= s; g1.w *= s; }
-      if (c0 + sc < g.Kd) x1 = ld4(g.B2 + (int64_t)(p / g.b_div) * g.ldb + c0 + sc);
+#pragma unroll
+    for (int j = 0; j < 32 / RPP; ++j) {
+      xst[j] = zero4();
+      const int i = m + xr + RPP * j;
+      if (i < cnt && c0 + xc < g.Kd) {
+        const int p = g.perm[beg + i];
+        xst[j] = ld4(g.B2 + (int64_t)(p / g.b_div) * g.ldb + c0 + xc);
+      }
     }
   };
   auto commit = [&]() {
-    st4(&Gs[sr * WS + sc], g0);
-    st4(&Gs[(sr + 16) * WS + sc], g1);
-    st4(&Xs[sr * WS + sc], x0);
-    st4(&Xs[(sr + 16) * WS + sc], x1);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) st4(&Gs[(sr + 16 * j) * GS + sc], gst[j]);
+#pragma unroll
+    for (int j = 0; j < 32 / RPP; ++j) st4(&Xs[(xr + RPP * j) * XS + xc], xst[j]);
   };
-  f32x16 acc = zero16();
+  f32x16 acc[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) acc[j] = zero16();
   float bsum = 0.f;
   if (cnt > 0) prefetch(0);
   for (int m = 0; m < cnt; m += 32) {
@@ -292,22 +339,26 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_kernel(GemmParams g) {
     commit();
     __syncthreads();
     if (m + 32 < cnt) prefetch(m + 32);
-    const float* gc = &Gs[(16 * hf) * WS + 32 * wm + ln];
-    const float* xc = &Xs[(16 * hf) * WS + 32 * wn + ln];
+    const float* gc = &Gs[(16 * hf) * GS + 32 * wm + ln];
+    const float* xc_ = &Xs[(16 * hf) * XS + 32 * NB * wn + ln];
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-      const float gv = gc[s * WS];
-      acc = mfma32(gv, xc[s * WS], acc);
+      const float gv = gc[s * GS];
+#pragma unroll
+      for (int j = 0; j < NB; ++j) acc[j] = mfma32(gv, xc_[s * XS + 32 * j], acc[j]);
       bsum += gv;
     }
   }
-  const int c = c0 + 32 * wn + ln;
-  if (c < g.Kd) {
-    float* dW = g.Y + (int64_t)e * g.N * g.Kd;
+  float* dW = g.Y + (int64_t)e * g.N * g.Kd;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int n = n0 + 32 * wm + acc_row(r, hf);
-      if (n < g.N) dW[(int64_t)n * g.Kd + c] = acc[r];
+  for (int j = 0; j < NB; ++j) {
+    const int c = c0 + 32 * NB * wn + 32 * j + ln;
+    if (c < g.Kd) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + 32 * wm + acc_row(r, hf);
+        if (n < g.N) dW[(int64_t)n * g.Kd + c] = acc[j][r];
+      }
     }
   }
   if (g.dbias && blockIdx.x == 0 && wn == 0) {
@@ -424,7 +475,8 @@ extern "C" int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const
   g.A = A; g.W = W; g.bias = bias; g.Y = Y; g.offsets = offsets; g.perm = perm;
   g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
   const unsigned mt = (unsigned)((P + 63) / 64 + E);
-  hipLaunchKernelGGL(grouped_nt_kernel, dim3(mt, (N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  // measured at the ViTMoE layer shape (P 8320, N = Kd = 1024, E 32): NB 1 0.207 ms, NB 2 0.240 ms
+  hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt, (N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), g);
   AMK_CHECK_LAUNCH("amk_grouped_gemm_nt");
   return AMK_OK;
 }
@@ -438,7 +490,9 @@ extern "C" int amk_grouped_gemm_nn(const float* A, int64_t lda, int a_div, const
   g.A = A; g.W = W; g.scale = scale; g.Y = Y; g.offsets = offsets; g.perm = perm;
   g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
   const unsigned mt = (unsigned)((P + 63) / 64 + E);
-  hipLaunchKernelGGL(grouped_nn_kernel, dim3(mt, (Kd + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  // same shape: NB 1 0.199 ms, NB 2 0.187 ms
+  if (Kd > 64) hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt, (Kd + 127) / 128), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  else hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt, 1), dim3(256), 0, static_cast<hipStream_t>(stream), g);
   AMK_CHECK_LAUNCH("amk_grouped_gemm_nn");
   return AMK_OK;
 }
@@ -453,7 +507,8 @@ extern "C" int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, co
   GemmParams g{};
   g.A = G; g.B2 = X; g.scale = scale; g.Y = dW; g.dbias = dbias; g.offsets = offsets; g.perm = perm;
   g.E = E; g.N = N; g.Kd = Kd; g.a_div = g_div; g.b_div = x_div; g.lda = ldg; g.ldb = ldx;
-  hipLaunchKernelGGL(grouped_wgrad_kernel, dim3((Kd + 63) / 64, (N + 63) / 64, E), dim3(256), 0,
+  // same shape: NB 1 0.218 ms, NB 2 0.231 ms
+  hipLaunchKernelGGL(grouped_wgrad_kernel<1>, dim3((Kd + 63) / 64, (N + 63) / 64, E), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g);
   AMK_CHECK_LAUNCH("amk_grouped_gemm_wgrad");
   return AMK_OK;

@@ -48,6 +48,26 @@ def main():
     x2 = x.detach().reshape(R, D)
     t_route = time_launches(lambda: ops.moe_route(logits.detach(), k), a.iters)
     print(f"   route (3 launches) {t_route*1e3:.3f} ms")
+    # individual ABI calls of the MoE layer
+    import ctypes
+    from amk import lib as L_
+    L = L_.load()
+    P_ = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    r = ops.moe_route(logits.detach(), k)
+    W = moe.experts_weight.detach(); bias = moe.experts_bias.detach()
+    P = R * k
+    Y = torch.empty(P, D, device=dev); dxp = torch.empty(P, D, device=dev); dW = torch.empty_like(W); db = torch.empty_like(bias)
+    d_out = cot.reshape(R, D).contiguous()
+    calls = {
+        "grouped_nt": lambda: L.amk_grouped_gemm_nt(P_(x2), D, k, P_(W), P_(bias), P_(r["offsets"]), P_(r["perm"]), P, E, D, D, P_(Y), st),
+        "grouped_nn": lambda: L.amk_grouped_gemm_nn(P_(d_out), D, k, P_(W), P_(r["gate"]), P_(r["offsets"]), P_(r["perm"]), P, E, D, D, P_(dxp), st),
+        "grouped_wgrad": lambda: L.amk_grouped_gemm_wgrad(P_(d_out), D, k, P_(x2), D, k, P_(r["gate"]), P_(r["offsets"]), P_(r["perm"]), P, E, D, D, P_(dW), P_(db), st),
+        "combine": lambda: L.amk_moe_combine(P_(Y), P_(r["ids"]), P_(r["gate"]), R, 1, k, D, P_(dxp), st),
+    }
+    for name, fn in calls.items():
+        t = time_launches(fn, a.iters)
+        print(f"   {name:14s} {t*1e3:8.3f} ms  {fl/t/1e12 if name.startswith('grouped') else 0:6.1f} TFLOP/s")
     sh = SwitchHeadAttention(D, h, 64, num_experts=E, sel_experts=k).to(dev)
     t_f = time_launches(lambda: sh(x), a.iters)
     t_fb = time_launches(fb(sh), a.iters)
