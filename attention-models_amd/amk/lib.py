@@ -33,6 +33,8 @@ SIGNATURES = {
     "amk_vq_gather": (_I, [_P, _P, _L, _I, _I, _P, _P]),
     "amk_agent_attn_fwd": (_I, [_P] * 9 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_agent_attn_bwd": (_I, [_P] * 14 + [_I] * 5 + [_L] * 21 + [_F, _P]),
+    "amk_swiglu_fwd": (_I, [_P, _L, _I, _P, _P]),
+    "amk_swiglu_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
     "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 7),
     "amk_grouped_gemm_nt": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "amk_grouped_gemm_nn": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),

@@ -31,7 +31,10 @@ class SwiGLU(nn.Module):
         self.w3 = nn.Linear(hidden_features, out_features, bias=bias)
 
     def forward(self, x):
-        a, b = self.w12(x).chunk(2, dim=-1)
+        ab = self.w12(x)  # (..., 2*hidden) = (a | b)
+        if ab.shape[-1] % 8 == 0:
+            return self.w3(ops.swiglu(ab))            # fused gate kernel (amk_swiglu_fwd / _bwd)
+        a, b = ab.chunk(2, dim=-1)                      # widths the kernel does not take (hidden % 4 != 0)
         return self.w3(F.silu(a) * b)
 
 

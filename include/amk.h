@@ -223,6 +223,16 @@ int amk_agent_attn_bwd(const float* q, const float* k, const float* v, const flo
                        int64_t dq_sb, int64_t dq_st, int64_t dq_sh, int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
                        int64_t dv_sb, int64_t dv_st, int64_t dv_sh, float scale, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Fused SwiGLU gate (epilogue of the ViT-VQGAN FFN):
+ *   out[m, j] = silu(ab[m, j]) * ab[m, H + j]      ab: (M, 2H) = w12(x), out: (M, H)
+ * replaces chunk -> silu -> mul of the SwiGLU the reference's FeedForward keywords describe
+ * (models/vitvqgan.py:20-34).  Backward writes d_ab (M, 2H) = (d_a | d_b) in one pass
+ * (no chunk-backward concatenation).  H must be a multiple of 4.
+ * -------------------------------------------------------------------------- */
+int amk_swiglu_fwd(const float* ab, int64_t M, int H, float* out, void* stream);
+int amk_swiglu_bwd(const float* ab, const float* d_out, int64_t M, int H, float* d_ab, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
