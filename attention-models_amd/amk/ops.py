@@ -21,6 +21,40 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Optional in-situ kernel timing: set to a dict and every hot-path ABI call is bracketed by two HIP
+# events on the launch stream (bench.py does this during its timed steps); None = no events.
+KERNEL_EVENTS = None
+
+
+class _timed:
+    """with _timed("name"): <one ABI call>  -- records (start, end) events when KERNEL_EVENTS is a dict."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if KERNEL_EVENTS is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        if KERNEL_EVENTS is not None:
+            self.b.record()
+            KERNEL_EVENTS.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
+def kernel_event_summary(events):
+    """{name: (launches, average ms)} after a device synchronize."""
+    out = {}
+    for name, pairs in events.items():
+        ms = [a.elapsed_time(b) for a, b in pairs]
+        out[name] = (len(ms), sum(ms) / len(ms))
+    return out
+
+
 def _require_device(*tensors):
     for t in tensors:
         if t is None:
@@ -82,11 +116,12 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale):
     o = _new_bthd(B, H, I, D, q)
     stats = torch.empty((B, H, I, 2), device=q.device, dtype=torch.float32)
     L = _lib.load()
-    rc = L.amk_attn_fwd(
-        _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(key_mask), _ptr(causal_mask),
-        B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
-        float(scale), _stream(),
-    )
+    with _timed("attn_fwd_kernel"):
+        rc = L.amk_attn_fwd(
+            _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(key_mask), _ptr(causal_mask),
+            B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
+            float(scale), _stream(),
+        )
     _lib.check(rc, "amk_attn_fwd")
     return q, k, v, o, stats
 
@@ -106,15 +141,24 @@ def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, sc
     if delta is None:
         delta = torch.empty((B, H, I), device=q.device, dtype=torch.float32)
     L = _lib.load()
-    rc = L.amk_attn_bwd(
-        _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(d_o),
-        _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), _ptr(key_mask), _ptr(causal_mask),
-        B, H, I, J, D,
-        *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o), *_strides4(d_o),
-        *_strides4(dq), *_strides4(dk), *_strides4(dv),
-        float(scale), int(stages), _stream(),
-    )
-    _lib.check(rc, "amk_attn_bwd")
+
+    def call(st):
+        rc = L.amk_attn_bwd(
+            _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(d_o),
+            _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), _ptr(key_mask), _ptr(causal_mask),
+            B, H, I, J, D,
+            *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o), *_strides4(d_o),
+            *_strides4(dq), *_strides4(dk), *_strides4(dv),
+            float(scale), int(st), _stream(),
+        )
+        _lib.check(rc, "amk_attn_bwd")
+
+    if KERNEL_EVENTS is not None and (stages & 1) and (stages & ~1):
+        call(1)  # delta on its own so that the events bracket the main kernel(s) only
+        with _timed("attn_bwd_fused_kernel" if stages & 8 else "attn_bwd_dkdv+dq"):
+            call(stages & ~1)
+    else:
+        call(stages)
 
 
 class _AttnCore(torch.autograd.Function):
@@ -229,10 +273,11 @@ class _VQLookup(torch.autograd.Function):
         zq = torch.empty((N, C), **f32)
         zn = torch.empty((N, C), **f32)
         partial = torch.empty((L.amk_vq_num_partials(N),), **f32)
-        rc = L.amk_vq_lookup_fwd(
-            _ptr(zf), _ptr(cb), N, K, C, nsplit, _ptr(en), _ptr(ee), _ptr(pmin), _ptr(pidx),
-            _ptr(idx), _ptr(out), _ptr(zq), _ptr(zn), _ptr(partial), _stream(),
-        )
+        with _timed("vq_lookup_fwd"):
+            rc = L.amk_vq_lookup_fwd(
+                _ptr(zf), _ptr(cb), N, K, C, nsplit, _ptr(en), _ptr(ee), _ptr(pmin), _ptr(pidx),
+                _ptr(idx), _ptr(out), _ptr(zq), _ptr(zn), _ptr(partial), _stream(),
+            )
         _lib.check(rc, "amk_vq_lookup_fwd")
         mean_sq = partial.sum() / float(N * C)
         # beta*mean((zq.detach()-z)^2) + mean((zq-z.detach())^2): the two means are one value
