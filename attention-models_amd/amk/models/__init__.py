@@ -3,9 +3,10 @@ classes on the hot path and their scaffolding."""
 from .attention import AgentAttention, SoftmaxAttention, SwitchHeadAttention
 from .model_factory import build_model
 from .moe import MoELayer
+from .muse import MUSE, BidirectionalDecoder
 from .vit import ViT
 from .vit_moe import ViTMoE
 from .vitvqgan import Codebook, ViTVQGAN
 
 __all__ = ["SoftmaxAttention", "AgentAttention", "SwitchHeadAttention", "MoELayer", "Codebook", "ViTVQGAN",
-           "ViT", "ViTMoE", "build_model"]
+           "ViT", "ViTMoE", "MUSE", "BidirectionalDecoder", "build_model"]

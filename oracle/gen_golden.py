@@ -106,8 +106,9 @@ def gen_softmax_attention(mods, meta):
         if "context" in kw:
             arrays[f"{vname}:gctx"] = gs[1]
             off = 2
-        for n, g in zip(pnames, gs[off:]):
-            arrays[f"{vname}:g:{n}"] = g
+        if vname in ("self_both", "cross_ctxmask"):  # parameter gradients for two variants (fixture size)
+            for n, g in zip(pnames, gs[off:]):
+                arrays[f"{vname}:g:{n}"] = g
     meta["softmax_attention"] = dict(bytes=save("softmax_attention", **arrays), variants=list(variants))
 
     # BASELINE.json configs[0]: dim 512, h 16, d 64, (B 2, T 128); weights/inputs from seeds,
@@ -338,6 +339,42 @@ def gen_vit_moe(mods, meta):
                                  n_params=sum(p.numel() for p in m.parameters()))
 
 
+def gen_muse_decoder(mods, meta):
+    muse = importlib.import_module("models.muse")  # imports transformers' CLIP classes, fetches nothing
+    cfg = dict(dim=64, codebook_size=256, n_heads=2, d_head=64, depth=2, mult=4, dropout=0.0, num_patches=16)
+    m = muse.BidirectionalDecoder(**cfg)
+    randomize_(m, 81)
+    g = torch.Generator().manual_seed(1001)
+    ids = torch.randint(0, cfg["codebook_size"] + 1, (2, 16), generator=g)
+    ctx = seeded((2, 7, 64), 1002).requires_grad_(True)
+    cmask = torch.ones(2, 7, dtype=torch.bool)
+    cmask[1, -2:] = False
+    tgt = torch.randint(0, cfg["codebook_size"], (2, 16), generator=g)
+    tgt[0, ::3] = -1
+    arrays = dict(np_state(m), ids=ids.numpy(), context=ctx.detach().numpy(), cmask=cmask.numpy(), tgt=tgt.numpy())
+    names = [n for n, _ in sorted(m.named_parameters())]
+    for vname, kw in {"plain": {}, "ctxmask": dict(context_mask=cmask)}.items():
+        logits = m(ids, context=ctx, **kw)
+        loss = F.cross_entropy(logits.transpose(1, 2), tgt, ignore_index=-1)
+        gs = torch.autograd.grad(loss, [ctx] + [p for _, p in sorted(m.named_parameters())], allow_unused=True)
+        arrays[f"{vname}:logits"] = logits.detach().numpy()
+        arrays[f"{vname}:loss"] = loss.detach().numpy()
+        arrays[f"{vname}:gctx"] = gs[0].numpy()
+        if vname == "plain":  # parameter gradients once (they dominate the fixture size)
+            for n, gr in zip(names, gs[1:]):
+                if gr is not None:
+                    arrays[f"{vname}:g:{n}"] = gr.numpy()
+    # helper functions of the sampling loop (deterministic parts)
+    lg = seeded((2, 5, 40), 1003)
+    arrays["filter_in"] = lg.numpy()
+    arrays["filter_out"] = muse.filter_logits(lg, p=0.9).numpy()
+    tt = torch.linspace(0, 1, 18)
+    arrays["cosine_t"] = tt.numpy()
+    arrays["cosine_out"] = muse.cosine_schedule(tt).numpy()
+    meta["muse_decoder_small"] = dict(bytes=save("muse_decoder_small", **arrays), cfg=cfg,
+                                      n_params=sum(p.numel() for p in m.parameters()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -353,6 +390,7 @@ def main():
     gen_agent(mods, meta)
     gen_vit(mods, meta)
     gen_vit_moe(mods, meta)
+    gen_muse_decoder(mods, meta)
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     total = sum(v["bytes"] for v in meta.values() if isinstance(v, dict) and "bytes" in v)

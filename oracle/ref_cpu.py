@@ -296,3 +296,23 @@ def vit_moe_forward(imgs, w, patch, n_heads, d_head, depth, n_experts, sel_exper
         sels.append((sv, so, sm))
     x = _ln(x, w, "norm")
     return x[:, 0] @ w["class_embed.weight"].t() + w["class_embed.bias"], sels
+
+
+# ------------------------------------------------------------------ masked-token decoder (Muse)
+def _gamma_ln(x, w, prefix):
+    return F.layer_norm(x, x.shape[-1:], w[prefix + ".gamma"], w[prefix + ".beta"])
+
+
+def bidirectional_decoder(ids, context, w, n_heads, d_head, depth, context_mask=None):
+    """BidirectionalDecoder.forward (models/muse.py:88-96) over transformer.Decoder
+    (models/transformer.py:87-135): per layer self-attention (no causal mask), cross-attention
+    onto `context`, GEGLU feed-forward, each pre-normed with a residual."""
+    x = w["token_emb.weight"][ids] + w["pos_enc"]
+    for i in range(depth):
+        lw = _sub(w, f"decoder.layers.{i}")
+        x = softmax_attention(_gamma_ln(x, lw, "norm1"), _sub(lw, "self_attn"), n_heads, d_head) + x
+        x = softmax_attention(_gamma_ln(x, lw, "norm2"), _sub(lw, "cross_attn"), n_heads, d_head,
+                              context=context, context_mask=context_mask) + x
+        x = _geglu_ffn(_gamma_ln(x, lw, "norm3"), _sub(lw, "feed_forward")) + x
+    x = _gamma_ln(x, w, "final_norm")
+    return x @ w["linear.weight"].t()

@@ -148,7 +148,8 @@ def test_module_matches_reference_golden(device, variant):
         assert_close(gs[1], fx[f"{variant}:gctx"], TOL, "grad context")
         off = 2
     for n, g in zip(names, gs[off:]):
-        assert_close(g, fx[f"{variant}:g:{n}"], TOL, f"grad {n}")
+        if f"{variant}:g:{n}" in fx:  # parameter gradients are stored for two of the variants
+            assert_close(g, fx[f"{variant}:g:{n}"], TOL, f"grad {n}")
 
 
 def test_module_config1(device):

@@ -106,3 +106,60 @@ def test_readme_shapes_and_factory(device):
     idx = vq.encode_imgs(imgs)
     assert idx.dtype == torch.int64 and tuple(idx.shape) == (2, vq.num_patches)
     assert tuple(vq.decode_indices(idx).shape) == (2, 3, 256, 256)
+
+
+@pytest.mark.parametrize("variant", ["plain", "ctxmask"])
+def test_muse_decoder_small_golden(device, variant):
+    """BASELINE.json configs[4]: the masked-token decoder (self- + cross-attention on the HIP kernels)
+    with the reference's weights: logits, cross-entropy loss, gradients."""
+    from amk.models import BidirectionalDecoder
+
+    fx, meta = load_golden("muse_decoder_small"), _meta("muse_decoder_small")
+    m = BidirectionalDecoder(**meta["cfg"])
+    res = m.load_state_dict(weights_of(fx), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    assert sum(p.numel() for p in m.parameters()) == meta["n_params"]
+    m = m.to(device)
+    ctx = torch.from_numpy(fx["context"]).to(device).requires_grad_(True)
+    kw = {} if variant == "plain" else dict(context_mask=torch.from_numpy(fx["cmask"]).to(device))
+    logits = m(torch.from_numpy(fx["ids"]).to(device), context=ctx, **kw)
+    assert_close(logits, fx[f"{variant}:logits"], 5e-5, "logits")
+    loss = torch.nn.functional.cross_entropy(logits.transpose(1, 2), torch.from_numpy(fx["tgt"]).to(device), ignore_index=-1)
+    assert_close(loss, fx[f"{variant}:loss"], 5e-5, "loss")
+    loss.backward()
+    _abs_close(ctx.grad, fx[f"{variant}:gctx"], 3e-4, "grad context")
+    for n, p in m.named_parameters():
+        if f"{variant}:g:{n}" in fx:
+            _abs_close(p.grad, fx[f"{variant}:g:{n}"], 3e-4, f"grad {n}")
+
+
+def test_muse_schedule_helpers_and_generate(device):
+    """cosine schedule / logit filter against the reference's outputs; fill_mask invariants; one
+    training loss and a full 18-step parallel decode (2 decoder passes per step) on the HIP path."""
+    from amk.models import MUSE, ViTVQGAN
+    from amk.models.muse import cosine_schedule, filter_logits
+
+    fx = load_golden("muse_decoder_small")
+    assert_close(cosine_schedule(torch.from_numpy(fx["cosine_t"])), fx["cosine_out"], 1e-6, "cosine_schedule")
+    got = filter_logits(torch.from_numpy(fx["filter_in"]).to(device), p=0.9).cpu().numpy()
+    assert (got == fx["filter_out"]).all()
+
+    torch.manual_seed(0)
+    vq = ViTVQGAN(dict(dim=64, img_size=32, patch_size=8, n_heads=1, d_head=64, depth=1, mlp_dim=64, dropout=0.0),
+                  dict(codebook_size=64, codebook_dim=32))
+    muse = MUSE(dim=64, vq=vq, text_dim=24, n_heads=1, d_head=64, depth=2, mult=4).to(device)
+    assert not any(p.requires_grad for p in muse.vq.parameters())          # frozen quantiser
+    tokens = torch.randint(0, 64, (5, 16), device=device)
+    inp, tgt = muse.fill_mask(tokens)
+    masked = inp == muse.mask_token_id
+    assert bool((masked.sum(-1) >= 1).all())
+    assert bool((tgt[~masked] == -1).all()) and bool((tgt[masked] == tokens[masked]).all()) and bool((inp[~masked] == tokens[~masked]).all())
+    text_hidden = torch.randn(2, 7, 24, device=device)
+    imgs = torch.rand(2, 3, 32, 32, device=device)
+    loss = muse(text_hidden, imgs)
+    loss.backward()
+    assert torch.isfinite(loss) and muse.decoder.linear.weight.grad is not None
+    out = muse.generate(text_hidden, timesteps=18)
+    assert tuple(out.shape) == (2, 3, 32, 32)
+    with pytest.raises(TypeError, match="CLIP"):
+        muse(["a photo"], imgs)
