@@ -1,0 +1,34 @@
+"""HIP-graph capture of a whole training step for launch-bound regimes.
+
+At small batch the routed-expert layers are dozens of short launches (ViTMoE, batch 2: ~600 kernels
+in 9 ms, most of it launch gaps).  The libamk.so entry points are graph-safe by construction --
+asynchronous on the caller's stream, no host synchronisation, no allocation, workspaces owned by
+the caller -- so the whole forward + backward + optimizer step can be captured once and replayed.
+torch owns the capture (torch.cuda.CUDAGraph = hipGraph on ROCm) and the static memory pool.
+"""
+import torch
+
+
+class GraphedStep:
+    """Capture ``fn(*static_inputs)`` (which may run forward, backward and optimizer.step) into a HIP
+    graph after `warmup` eager runs on a side stream; ``replay(*new_inputs)`` copies the inputs into
+    the static buffers and launches the graph.  `fn` must not synchronise with the host; optimizers
+    need ``capturable=True``."""
+
+    def __init__(self, fn, static_inputs, warmup=3):
+        self.static_inputs = [t.clone() for t in static_inputs]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                fn(*self.static_inputs)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_outputs = fn(*self.static_inputs)
+
+    def replay(self, *inputs):
+        for dst, src in zip(self.static_inputs, inputs):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.static_outputs
