@@ -35,7 +35,8 @@ SIGNATURES = {
     "amk_agent_attn_bwd": (_I, [_P] * 14 + [_I] * 5 + [_L] * 21 + [_F, _P]),
     "amk_swiglu_fwd": (_I, [_P, _L, _I, _P, _P]),
     "amk_swiglu_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
-    "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 7),
+    "amk_moe_route_ws_ints": (_L, [_L, _I, _I]),
+    "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 8),
     "amk_grouped_gemm_nt": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "amk_grouped_gemm_nn": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "amk_grouped_gemm_wgrad": (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),

@@ -342,11 +342,12 @@ def moe_route(logits2, k):
     dev = logits2.device
     ids = torch.empty((U, k), device=dev, dtype=torch.int64)
     gate = torch.empty((U, k), device=dev, dtype=torch.float32)
-    counts, rank = _i32(E, dev), _i32(U * k, dev)
-    offsets, perm = _i32(E + 1, dev), _i32(U * k, dev)
     L = _lib.load()
+    counts, rank = _i32(E, dev), _i32(U * k, dev)
+    blockhist = _i32(L.amk_moe_route_ws_ints(U, E, k), dev)
+    offsets, perm = _i32(E + 1, dev), _i32(U * k, dev)
     rc = L.amk_moe_route(_ptr(logits2.contiguous()), U, E, k, _ptr(ids), _ptr(gate), _ptr(counts), _ptr(rank),
-                         _ptr(offsets), _ptr(perm), _stream())
+                         _ptr(blockhist), _ptr(offsets), _ptr(perm), _stream())
     _lib.check(rc, "amk_moe_route")
     return dict(ids=ids, gate=gate, offsets=offsets, perm=perm)
 

@@ -9,9 +9,9 @@
 //   route_topk     : per routed unit (a token, or a (token, head)), top-k of its E gate logits
 //                    (descending, lowest index on ties = torch.topk on distinct values) and
 //                    sigmoid of the selected logits.
-//   route_rank     : one wave per expert scans the ids with ballots: counts[e] and each pair's
-//                    rank inside its expert, in ascending pair order (deterministic).
-//   route_perm     : exclusive scan of the counts -> offsets[E+1]; perm[offsets[e]+rank] = pair.
+//   route_local / route_scan / route_perm : block-local ranks + per-block histograms, per-expert scan
+//                    of the histograms, then perm[offsets[e] + block base + rank] = pair -- pairs of an
+//                    expert in ascending pair order (deterministic), no serial pass over the pairs.
 //   grouped_nt     : Y[p,:]  = A[p/a_div,:] * W_e^T (+ b_e)          (forward of x W^T + b)
 //   grouped_nn     : Y[p,:]  = s[p] * (A[p/a_div,:] * W_e)           (input gradient)
 //   grouped_wgrad  : dW_e    = sum_{p in e} s[p] * G[p/a_div,:]^T (x) X[p/b_div,:]  (+ db_e)
@@ -64,35 +64,62 @@ __global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict
   }
 }
 
-__global__ __launch_bounds__(64) void route_rank_kernel(const int64_t* __restrict__ ids, int64_t P,
-                                                        int32_t* __restrict__ counts, int32_t* __restrict__ rank) {
-  const int e = blockIdx.x;
-  const int lane = threadIdx.x;
-  int base = 0;
-  for (int64_t p0 = 0; p0 < P; p0 += 64) {
-    const int64_t p = p0 + lane;
-    const bool hit = (p < P) && (ids[p] == e);
-    const unsigned long long m = __ballot(hit);
-    if (hit) rank[p] = base + __popcll(m & ((1ull << lane) - 1ull));
-    base += __popcll(m);
+// Deterministic expert-major ordering in three small launches (no serial scan over the pairs):
+//   route_local : a block takes 256 consecutive pairs; rank of a pair among the EARLIER pairs of the
+//                 same expert inside the block (LDS broadcast compare loop) + the block's histogram.
+//   route_scan  : per expert, exclusive scan of the block histograms -> block bases, counts, offsets.
+//   route_perm  : perm[offsets[e] + base[block][e] + local rank] = pair.
+// Pairs of one expert therefore appear in ascending pair order, whatever the launch timing.
+__global__ __launch_bounds__(256) void route_local_kernel(const int64_t* __restrict__ ids, int64_t P, int E,
+                                                          int32_t* __restrict__ rank, int32_t* __restrict__ blockhist) {
+  __shared__ int sid[256];
+  const int tid = threadIdx.x;
+  const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+  const int my = (p < P) ? (int)ids[p] : -1;
+  sid[tid] = my;
+  __syncthreads();
+  int r = 0;
+  for (int j = 0; j < tid; ++j) r += (sid[j] == my);
+  if (p < P) rank[p] = r;
+  // histogram: the LAST pair of each expert in the block knows the count (its rank + 1)
+  int32_t* bh = blockhist + (int64_t)blockIdx.x * E;
+  for (int e = tid; e < E; e += 256) bh[e] = 0;
+  __syncthreads();
+  if (my >= 0) {
+    bool last = true;
+    for (int j = tid + 1; j < 256; ++j) last &= (sid[j] != my);
+    if (last) bh[my] = r + 1;
   }
-  if (lane == 0) counts[e] = base;
 }
 
-__global__ __launch_bounds__(256) void route_perm_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ counts,
-                                                         const int32_t* __restrict__ rank, int64_t P, int E,
-                                                         int32_t* __restrict__ offsets, int32_t* __restrict__ perm) {
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+__global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ blockhist, int nblk, int E,
+                                                         int32_t* __restrict__ counts, int32_t* __restrict__ offsets) {
+  __shared__ int total[1024];
+  for (int e = threadIdx.x; e < E; e += 256) {  // one thread per expert walks the blocks in order
     int acc = 0;
-    for (int e = 0; e < E; ++e) { offsets[e] = acc; acc += counts[e]; }
+    for (int b = 0; b < nblk; ++b) {
+      const int c = blockhist[(int64_t)b * E + e];
+      blockhist[(int64_t)b * E + e] = acc;  // exclusive: base of this block inside the expert
+      acc += c;
+    }
+    counts[e] = acc;
+    total[e] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int acc = 0;
+    for (int e = 0; e < E; ++e) { offsets[e] = acc; acc += total[e]; }
     offsets[E] = acc;
   }
+}
+
+__global__ __launch_bounds__(256) void route_perm_kernel(const int64_t* __restrict__ ids, const int32_t* __restrict__ offsets,
+                                                         const int32_t* __restrict__ blockbase, const int32_t* __restrict__ rank,
+                                                         int64_t P, int E, int32_t* __restrict__ perm) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const int e = (int)ids[p];
-  int off = 0;
-  for (int j = 0; j < e; ++j) off += counts[j];
-  perm[off + rank[p]] = (int)p;
+  perm[offsets[e] + blockbase[(int64_t)blockIdx.x * E + e] + rank[p]] = (int)p;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -438,18 +465,23 @@ using namespace amk_moe;
 
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+extern "C" int64_t amk_moe_route_ws_ints(int64_t U, int E, int k) { return ((U * k + 255) / 256) * E; }
+
 extern "C" int amk_moe_route(const float* logits, int64_t U, int E, int k,
-                             int64_t* ids, float* gate, int32_t* counts, int32_t* rank,
+                             int64_t* ids, float* gate, int32_t* counts, int32_t* rank, int32_t* blockhist,
                              int32_t* offsets, int32_t* perm, void* stream) {
-  AMK_CHECK_ARG(logits && ids && gate && counts && rank && offsets && perm, "amk_moe_route: null pointer");
+  AMK_CHECK_ARG(logits && ids && gate && counts && rank && blockhist && offsets && perm, "amk_moe_route: null pointer");
+  AMK_CHECK_SUPPORTED(E <= 1024, "amk_moe_route: at most 1024 experts");
   AMK_CHECK_ARG(U > 0 && E > 0 && k > 0 && k <= E, "amk_moe_route: bad sizes U=%lld E=%d k=%d", (long long)U, E, k);
   AMK_CHECK_SUPPORTED(k <= MAX_K, "amk_moe_route: sel_experts %d > %d", k, MAX_K);
   const int64_t P = U * k;
   AMK_CHECK_SUPPORTED(P < (1ll << 31), "amk_moe_route: too many routed pairs");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(route_topk_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, logits, U, E, k, ids, gate);
-  hipLaunchKernelGGL(route_rank_kernel, dim3(E), dim3(64), 0, st, ids, P, counts, rank);
-  hipLaunchKernelGGL(route_perm_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, ids, counts, rank, P, E, offsets, perm);
+  const int nblk = (int)((P + 255) / 256);
+  hipLaunchKernelGGL(route_local_kernel, dim3(nblk), dim3(256), 0, st, ids, P, E, rank, blockhist);
+  hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(256), 0, st, blockhist, nblk, E, counts, offsets);
+  hipLaunchKernelGGL(route_perm_kernel, dim3(nblk), dim3(256), 0, st, ids, offsets, blockhist, rank, P, E, perm);
   AMK_CHECK_LAUNCH("amk_moe_route");
   return AMK_OK;
 }

@@ -155,9 +155,11 @@ int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, i
  *   logits (U,E) -> ids int64 (U,k) descending by logit (lowest index on equal logits),
  *   gate (U,k) = sigmoid(selected logit); offsets int32 (E+1), perm int32 (U*k): pairs grouped
  *   by expert, ascending pair index inside an expert (deterministic).
- *   Workspaces: counts int32 (E), rank int32 (U*k).  k <= 8. */
+ *   Workspaces: counts int32 (E), rank int32 (U*k), blockhist int32 (amk_moe_route_ws_ints(U,E,k)).
+ *   k <= 8, E <= 1024. */
+int64_t amk_moe_route_ws_ints(int64_t U, int E, int k);
 int amk_moe_route(const float* logits, int64_t U, int E, int k,
-                  int64_t* ids, float* gate, int32_t* counts, int32_t* rank,
+                  int64_t* ids, float* gate, int32_t* counts, int32_t* rank, int32_t* blockhist,
                   int32_t* offsets, int32_t* perm, void* stream);
 
 /* Y[p,:] = A[p / a_div, :] * W[e(p)]^T (+ bias[e(p)]) for every pair: the expert Linear layers
