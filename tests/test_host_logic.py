@@ -1,0 +1,102 @@
+"""Host-side logic that needs no GPU: checkpoint-key compatibility of every drop-in class with the
+reference's state_dict (taken from the golden fixtures the reference produced), the routing / mask /
+schedule helpers, the gradient-bucket layout."""
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from util import GOLDEN, load_golden, weights_of
+
+
+def _meta(name):
+    return json.load(open(os.path.join(GOLDEN, "golden_meta.json")))[name]
+
+
+def _roundtrip(module, fx):
+    ref = weights_of(fx)
+    res = module.load_state_dict(ref, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    out = module.state_dict()
+    assert set(out) == set(ref)                      # same key set as the reference's checkpoint
+    for k in ref:
+        assert torch.equal(out[k].cpu(), ref[k]), k  # and the values survive the stacking translation
+
+
+def test_state_dict_keys_match_reference_checkpoints():
+    from amk.models import (AgentAttention, BidirectionalDecoder, MoELayer, SoftmaxAttention, SwitchHeadAttention, ViT,
+                            ViTMoE, ViTVQGAN)
+
+    fx = load_golden("softmax_attention"); d = [int(v) for v in fx["dims"]]
+    _roundtrip(SoftmaxAttention(d[0], d[1], d[2]), fx)
+    fx = load_golden("moe_small"); d = [int(v) for v in fx["dims"]]
+    _roundtrip(MoELayer(d[0], d[0], d[1], d[2]), fx)
+    fx = load_golden("switchhead_small"); d = [int(v) for v in fx["dims"]]
+    _roundtrip(SwitchHeadAttention(d[0], d[1], d[2], num_experts=d[3], sel_experts=d[4]), fx)
+    fx = load_golden("agent_small"); d = [int(v) for v in fx["dims"]]
+    _roundtrip(AgentAttention(d[0], d[1], d[2], agent_num=d[3]), fx)
+    m = _meta("vitvqgan_small")
+    _roundtrip(ViTVQGAN(m["cfg"], m["codebook"]), load_golden("vitvqgan_small"))
+    _roundtrip(ViT(**_meta("vit_small")["cfg"]), load_golden("vit_small"))
+    _roundtrip(ViTMoE(**_meta("vit_moe_small")["cfg"]), load_golden("vit_moe_small"))
+    _roundtrip(BidirectionalDecoder(**_meta("muse_decoder_small")["cfg"]), load_golden("muse_decoder_small"))
+
+
+def test_constructor_contracts():
+    from amk.models import AgentAttention, MoELayer, ViT
+
+    with pytest.raises(ValueError, match="num_heads"):
+        AgentAttention(384, 8, 64, agent_num=47)       # the reference's einsum fails there too
+    assert AgentAttention(384, 6, 64).pool_size == 6
+    with pytest.raises(ValueError, match="output_dim"):
+        MoELayer(64, 32, 4, 2)
+    v = ViT(dim=64, image_size=32, patch_size=8, n_heads=1, d_head=64, depth=1, mlp_dim=128, dropout=0.0, num_classes=3)
+    assert v.encoder.layers[0].feed_forward.ff[0].weight.shape == (0, 64)   # mult = dropout quirk
+
+
+def test_vq_nsplit_and_masks():
+    from amk import ops
+
+    for N, K in [(1, 32), (2048, 8192), (32768, 8192), (10 ** 6, 8192), (128, 64), (5000, 96)]:
+        s = ops.vq_nsplit(N, K)
+        assert s >= 1 and K % (32 * s) == 0 and (s == 1 or K // s >= 256)
+    m = ops._mask_u8(torch.ones(1, 1, 5, 7, dtype=torch.bool), (5, 7), "causal_mask")
+    assert m.dtype == torch.uint8 and tuple(m.shape) == (5, 7) and m.is_contiguous()
+    assert tuple(ops._mask_u8(torch.ones(1, 7, dtype=torch.bool), (5, 7), "causal_mask").shape) == (5, 7)  # broadcast rows
+    with pytest.raises(RuntimeError):
+        ops._mask_u8(torch.ones(2, 3, 4, dtype=torch.bool), (3, 4), "context_mask")
+    assert ops._mask_u8(None, (2, 2), "x") is None
+
+
+def test_lr_schedule_matches_timm_formula():
+    from amk.train import cosine_warmup_lr
+
+    base, t_init, warm = 1e-4, 100000, 50000
+    assert cosine_warmup_lr(0, base, t_init, warm) == pytest.approx(1e-6)
+    assert cosine_warmup_lr(25000, base, t_init, warm) == pytest.approx(1e-6 + 25000 * (base - 1e-6) / warm)
+    for t in (50000, 75000, 100000):
+        want = 5e-5 + 0.5 * (base - 5e-5) * (1 + math.cos(math.pi * t / t_init))
+        assert cosine_warmup_lr(t, base, t_init, warm) == pytest.approx(want)
+
+
+def test_grad_reducer_bucket_layout():
+    """Reverse registration order, grads are views of the flat buckets, unused parameters included."""
+    from amk.dp import GradReducer
+
+    net = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.Linear(16, 4), torch.nn.Linear(4, 4))
+    red = GradReducer(net.parameters(), bucket_bytes=16 * 4 * 4)
+    params = list(net.parameters())
+    assert red.buckets[0].params[0] is params[-1]                 # last registered parameter first
+    assert sum(len(b.params) for b in red.buckets) == len(params)
+    for b in red.buckets:
+        for p, v in zip(b.params, b.views):
+            assert p.grad.data_ptr() == v.data_ptr() and v.data_ptr() >= b.flat.data_ptr()
+    red.begin()
+    net[:2](torch.randn(3, 8)).sum().backward()                   # the last layer gets no gradient
+    red.finish()
+    assert float(params[-1].grad.abs().sum()) == 0.0 and float(params[0].grad.abs().sum()) > 0.0
+    red.zero_grad()
+    assert all(float(b.flat.abs().sum()) == 0.0 for b in red.buckets)
+    assert red.grads_nbytes() == sum(p.numel() for p in params) * 4
