@@ -441,8 +441,9 @@ class _AgentAttn(torch.autograd.Function):
         stats1 = torch.empty((B, H, P, 2), device=dev, dtype=torch.float32)
         cw, cb = conv_w.contiguous(), conv_b.contiguous()
         L = _lib.load()
+        ws = torch.empty((L.amk_agent_ws_floats(B, H, T, P, 0),), device=dev, dtype=torch.float32)
         rc = L.amk_agent_attn_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(cw), _ptr(cb), _ptr(o), _ptr(agents), _ptr(vagent),
-                                  _ptr(stats1), B, H, T, D, P, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
+                                  _ptr(stats1), _ptr(ws), B, H, T, D, P, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
                                   float(scale), _stream())
         _lib.check(rc, "amk_agent_attn_fwd")
         ctx.save_for_backward(qkv2, cw, agents, vagent, stats1)
@@ -461,12 +462,13 @@ class _AgentAttn(torch.autograd.Function):
         dqkv2 = torch.empty_like(qkv2)
         dqkv = dqkv2.view(B, T, 3, H, D)
         dq, dk, dv = (dqkv[:, :, j].permute(0, 2, 1, 3) for j in range(3))
-        dag = torch.empty_like(agents)
-        dw_part = torch.empty((B * H, 9, D), device=dev, dtype=torch.float32)
-        db_part = torch.empty((B * H, D), device=dev, dtype=torch.float32)
         L = _lib.load()
+        cells = B * H * L.amk_agent_num_chunks(T)
+        ws = torch.empty((L.amk_agent_ws_floats(B, H, T, P, 1),), device=dev, dtype=torch.float32)
+        dw_part = torch.empty((cells, 9, D), device=dev, dtype=torch.float32)
+        db_part = torch.empty((cells, D), device=dev, dtype=torch.float32)
         rc = L.amk_agent_attn_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(cw), _ptr(d_o), _ptr(agents), _ptr(vagent), _ptr(stats1),
-                                  _ptr(dq), _ptr(dk), _ptr(dv), _ptr(dag), _ptr(dw_part), _ptr(db_part),
+                                  _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), _ptr(dw_part), _ptr(db_part),
                                   B, H, T, D, P, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(d_o),
                                   *_strides4(dq), *_strides4(dk), *_strides4(dv), float(scale), _stream())
         _lib.check(rc, "amk_agent_attn_bwd")

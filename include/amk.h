@@ -204,21 +204,29 @@ int amk_moe_gate_grad(const float* d_out, const float* Y, const int64_t* ids, co
  * q,k,v,o addressed like amk_attn_fwd (T rows).  Saved for the backward: agents (B,H,P,D),
  * vagent (B,H,P,D), stats1 (B,H,P,2) = {row max, row sum} of the aggregation softmax.
  * D must be 64, P <= 16, P <= T.
+ * The sequence is processed in chunks of 256 tokens, one workgroup per (batch, head, chunk);
+ * sums over tokens go through per-chunk partials in the caller's workspace `ws`
+ * (amk_agent_ws_floats(B,H,T,P,backward) floats, contents undefined on return) and are folded
+ * in chunk order, so results are bitwise reproducible.
  * -------------------------------------------------------------------------- */
+int amk_agent_num_chunks(int T);                                  /* ceil(T / 256); 0 for T <= 0 */
+int64_t amk_agent_ws_floats(int B, int H, int T, int P, int backward); /* workspace size in floats */
+
 int amk_agent_attn_fwd(const float* q, const float* k, const float* v, const float* conv_w, const float* conv_b,
-                       float* o, float* agents, float* vagent, float* stats1,
+                       float* o, float* agents, float* vagent, float* stats1, float* ws,
                        int B, int H, int T, int D, int P,
                        int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
                        int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
                        float scale, void* stream);
 
 /* Backward of amk_agent_attn_fwd: dq, dk, dv fully overwritten (q/k/v-like addressing);
- * dconvw_part (B*H, 9, D) and dconvb_part (B*H, D) are per-(batch, head) partial sums of the
- * convolution weight / bias gradients (the caller sums over the first axis; weight element
- * [c][0][a][b] is partial [.., a*3+b, c]); dagents_ws: workspace (B,H,P,D). */
+ * dconvw_part (B*H*NC, 9, D) and dconvb_part (B*H*NC, D), NC = amk_agent_num_chunks(T), are
+ * per-(batch, head, chunk) partial sums of the convolution weight / bias gradients (the caller
+ * sums over the first axis; weight element [c][0][a][b] is partial [.., a*3+b, c]);
+ * ws: amk_agent_ws_floats(B,H,T,P,1) floats. */
 int amk_agent_attn_bwd(const float* q, const float* k, const float* v, const float* conv_w, const float* d_o,
                        const float* agents, const float* vagent, const float* stats1,
-                       float* dq, float* dk, float* dv, float* dagents_ws, float* dconvw_part, float* dconvb_part,
+                       float* dq, float* dk, float* dv, float* ws, float* dconvw_part, float* dconvb_part,
                        int B, int H, int T, int D, int P,
                        int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
                        int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t do_sb, int64_t do_st, int64_t do_sh,

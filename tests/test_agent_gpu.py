@@ -40,9 +40,11 @@ def test_agent_small_golden(device):
         _abs_close(p.grad, fx["g:" + n], TOL, f"grad {n}")
 
 
-@pytest.mark.parametrize("B,T,dim,h,agent_num", [(2, 10, 384, 6, 47), (1, 1024, 384, 6, 47), (2, 65, 256, 4, 16), (1, 300, 128, 2, 4), (1, 37, 64, 1, 1)])
+@pytest.mark.parametrize("B,T,dim,h,agent_num", [(2, 10, 384, 6, 47), (1, 1024, 384, 6, 47), (2, 65, 256, 4, 16), (1, 300, 128, 2, 4), (1, 37, 64, 1, 1),
+                                                   (1, 513, 128, 2, 4), (2, 256, 192, 3, 9)])
 def test_agent_vs_oracle(device, B, T, dim, h, agent_num):
-    """README.md:116-127 shape (2,10,384) h=6, the BASELINE.md T=1024 case, ragged bins (T % p != 0)."""
+    """README.md:116-127 shape (2,10,384) h=6, the BASELINE.md T=1024 case, ragged bins (T % p != 0),
+    a last chunk of one token (513 = 2*256 + 1) and an exactly full chunk."""
     from amk.models import AgentAttention
 
     d = 64
