@@ -4,18 +4,23 @@
 // agent tokens per head, agent aggregation softmax((A*scale) K^T) V, agent broadcast
 // softmax((q*scale) A^T) V_agent, plus a depthwise 3x3 convolution of v over the
 // (head, token) plane.  With p <= 16 agents the work is O(T*p*d) per head -- HBM/VALU bound,
-// nowhere near a GEMM.  The sequence is cut into 256-token chunks and every kernel runs one
-// workgroup per (batch, head, chunk) -- B*h*ceil(T/256) workgroups, so a (2, 1024) call still
-// spreads over 48 CUs and a (64, 1024) call over-subscribes the chip 6x -- with the sums over
+// nowhere near a GEMM.  The sequence is cut into 128-token chunks and every kernel runs one
+// workgroup per (batch, head, chunk) -- B*h*ceil(T/128) workgroups, so a (2, 1024) call still
+// spreads over 96 CUs and a (64, 1024) call over-subscribes the chip 12x -- with the sums over
 // tokens (agent aggregation, dV_agent, dA, conv weight gradients) written as per-chunk partials
 // and folded by tiny combine kernels in fixed chunk order (deterministic, no atomics):
 //     forward : pool -> s1_partial -> s1_combine -> s2
 //     backward: s2_bwd -> mid -> s1_bwd -> pool_bwd
-// Two thread mappings per chunk:
-//     phase A  thread <-> token : the p dot products of a q/k row against the agents
-//                                 (agents broadcast from LDS), the p-wide softmaxes
-//     phase B  lane   <-> channel: sums over tokens (coalesced 256-B row reads), the
-//                                 depthwise convolution, coalesced O stores
+// Every global access is a coalesced b128 with 16 lanes per 256-byte row.  Two thread mappings
+// per chunk:
+//     phase A  2 threads <-> token: the chunk's q/k/v/dO rows are staged in an LDS tile (row
+//                                 stride 68 floats); each thread takes 32 channels of its token
+//                                 against the agents (broadcast from LDS), the pair adds up with
+//                                 one DPP swap; the p-wide softmaxes; dq / dk rows leave through
+//                                 the same tile
+//     phase B  16 lanes <-> row  : sums over tokens, the depthwise convolution (its 3x3 halo
+//                                 comes from L2), O / dv stores; sums fold over the 4 row
+//                                 groups of a wave by DPP and over the 4 waves through LDS
 // bias1 / bias2 are scalars added to every score of a softmax row: the softmax is invariant
 // to them, so they do not enter the arithmetic and their gradient is exactly 0.
 #include "amk_common.h"
@@ -24,8 +29,11 @@ namespace amk_agent {
 
 constexpr int D = 64;
 constexpr int MAXP = 16;
-constexpr int CH = 256;  // tokens per chunk = threads per workgroup
+constexpr int CH = 128;      // tokens per chunk
+constexpr int NT = 256;      // threads per workgroup: 2 per token in phase A, 16 per row in phase B
+constexpr int TS = 68;       // LDS row stride of the staged tile (conflict-free b128 row reads)
 constexpr int PSTR = D + 2;  // forward partial record per (chunk, agent): D sums, chunk max, chunk row sum
+constexpr int HALF = D / 2;
 
 struct Strides { int64_t sb, st, sh; };
 
@@ -54,45 +62,61 @@ struct BwdParams {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
-__device__ __forceinline__ int bin_lo(int i, int T, int P) { return (int)(((int64_t)i * T) / P); }
-__device__ __forceinline__ int bin_hi(int i, int T, int P) { return (int)((((int64_t)(i + 1)) * T + P - 1) / P); }
+__device__ __forceinline__ float4 f4(float x) { return make_float4(x, x, x, x); }
+__device__ __forceinline__ void fma4(float4& a, float s, const float4& x) {
+  a.x += s * x.x; a.y += s * x.y; a.z += s * x.z; a.w += s * x.w;
+}
+__device__ __forceinline__ void mad4(float4& a, const float4& w, const float4& x) {
+  a.x += w.x * x.x; a.y += w.y * x.y; a.z += w.z * x.z; a.w += w.w * x.w;
+}
+__host__ __device__ __forceinline__ int bin_lo(int i, int T, int P) { return (int)(((int64_t)i * T) / P); }
+__host__ __device__ __forceinline__ int bin_hi(int i, int T, int P) { return (int)((((int64_t)(i + 1)) * T + P - 1) / P); }
 
-__device__ __forceinline__ void load_row(const float* p, bool ok, float (&r)[D]) {
+// Workgroup-cooperative: rows [t0, t0+CH) of a (T, D) view -> tile[CH][TS]; rows >= T are zero.
+// 16 lanes per 256-byte row, 16 rows per pass: coalesced b128 loads, conflict-free LDS writes.
+__device__ __forceinline__ void stage_rows(float* tile, const float* base, int64_t st, int t0, int T, int tid) {
+  const int c4 = (tid & 15) * 4;
 #pragma unroll
-  for (int c4 = 0; c4 < D / 4; ++c4) {
-    const float4 t = ok ? ld4(p + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    r[4 * c4] = t.x; r[4 * c4 + 1] = t.y; r[4 * c4 + 2] = t.z; r[4 * c4 + 3] = t.w;
+  for (int r0 = 0; r0 < CH; r0 += NT / 16) {
+    const int r = r0 + (tid >> 4), t = t0 + r;
+    st4(tile + r * TS + c4, t < T ? ld4(base + (int64_t)t * st + c4) : f4(0.f));
   }
 }
-
-__device__ __forceinline__ float dot_row(const float (&r)[D], const float* a) {
+// tile[CH][TS] -> rows [t0, min(t0+CH, T)) of a (T, D) view
+__device__ __forceinline__ void unstage_rows(const float* tile, float* base, int64_t st, int t0, int T, int tid) {
+  const int c4 = (tid & 15) * 4;
+#pragma unroll
+  for (int r0 = 0; r0 < CH; r0 += NT / 16) {
+    const int r = r0 + (tid >> 4), t = t0 + r;
+    if (t < T) st4(base + (int64_t)t * st + c4, ld4(tile + r * TS + c4));
+  }
+}
+// phase A: thread (tok, half) owns channels [32*half, 32*half+32) of token tok
+__device__ __forceinline__ void load_half(const float* tile, int tok, int half, float (&r)[HALF]) {
+  const float* src = tile + tok * TS + HALF * half;
+#pragma unroll
+  for (int j = 0; j < HALF / 4; ++j) {
+    const float4 t = ld4(src + 4 * j);
+    r[4 * j] = t.x; r[4 * j + 1] = t.y; r[4 * j + 2] = t.z; r[4 * j + 3] = t.w;
+  }
+}
+// <row half, a[32*half ...]> summed over the two halves of the token (lanes 2k, 2k+1)
+__device__ __forceinline__ float dot_half(const float (&r)[HALF], const float* a, int half) {
+  const float* src = a + HALF * half;
   float s = 0.f;
 #pragma unroll
-  for (int c4 = 0; c4 < D / 4; ++c4) {
-    const float4 t = ld4(a + 4 * c4);  // same address in every lane: LDS broadcast
-    s += r[4 * c4] * t.x + r[4 * c4 + 1] * t.y + r[4 * c4 + 2] * t.z + r[4 * c4 + 3] * t.w;
+  for (int j = 0; j < HALF / 4; ++j) {
+    const float4 t = ld4(src + 4 * j);
+    s += r[4 * j] * t.x + r[4 * j + 1] * t.y + r[4 * j + 2] * t.z + r[4 * j + 3] * t.w;
   }
-  return s;
+  return s + __shfl_xor(s, 1, 64);
 }
-
-// depthwise 3x3 over the (head, token) plane, zero padded: channel c = lane
-__device__ __forceinline__ float conv_at(const float* vb, const Strides& vs, int H, int T, int hh, int t, int c,
-                                         const float (&w)[9], float bias) {
-  float acc = bias;
-#pragma unroll
-  for (int a = 0; a < 3; ++a) {
-    const int h2 = hh + a - 1;
-    if (h2 < 0 || h2 >= H) continue;
-#pragma unroll
-    for (int b = 0; b < 3; ++b) {
-      const int t2 = t + b - 1;
-      if (t2 < 0 || t2 >= T) continue;
-      acc += w[a * 3 + b] * vb[(int64_t)h2 * vs.sh + (int64_t)t2 * vs.st + c];
-    }
-  }
-  return acc;
+// sum over the four 16-lane row groups of a wave (phase B: lane bits 4, 5 select the token)
+__device__ __forceinline__ float4 fold_subs(float4 a) {
+  a.x += __shfl_xor(a.x, 16, 64); a.y += __shfl_xor(a.y, 16, 64); a.z += __shfl_xor(a.z, 16, 64); a.w += __shfl_xor(a.w, 16, 64);
+  a.x += __shfl_xor(a.x, 32, 64); a.y += __shfl_xor(a.y, 32, 64); a.z += __shfl_xor(a.z, 32, 64); a.w += __shfl_xor(a.w, 32, 64);
+  return a;
 }
-
 // sum of the four waves' entries red[(w*MAXP + i)*D + lane]
 __device__ __forceinline__ float fold4(const float* red, int i, int lane) {
   return red[(0 * MAXP + i) * D + lane] + red[(1 * MAXP + i) * D + lane] + red[(2 * MAXP + i) * D + lane] +
@@ -111,18 +135,22 @@ __device__ __forceinline__ Where where(int H, int NC) {
 
 // ---------------------------------------------------------------------------------------
 // forward 0: agent tokens = mean of q over the adaptive bin (AdaptiveAvgPool2d over (t, h), h == p).
-// One workgroup per (b, h, agent).
-__global__ __launch_bounds__(256) void agent_pool_kernel(Params p) {
-  __shared__ float red[4 * D];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// One workgroup per (b, h, agent); 16 rows per pass.
+__global__ __launch_bounds__(NT) void agent_pool_kernel(Params p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * D];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, c4 = (tid & 15) * 4;
   const int i = blockIdx.x % p.P;
   const int bh = blockIdx.x / p.P;
   const int h = bh % p.H, b = bh / p.H;
   const float* qb = p.q + (int64_t)b * p.qs.sb + (int64_t)h * p.qs.sh;
   const int lo = bin_lo(i, p.T, p.P), hi = bin_hi(i, p.T, p.P);
-  float s = 0.f;
-  for (int t = lo + wave; t < hi; t += 4) s += qb[(int64_t)t * p.qs.st + lane];
-  red[wave * D + lane] = s;
+  float4 s = f4(0.f);
+  for (int t = lo + (tid >> 4); t < hi; t += NT / 16) {
+    const float4 x = ld4(qb + (int64_t)t * p.qs.st + c4);
+    s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+  }
+  s = fold_subs(s);
+  if (lane < 16) st4(&red[wave * D + c4], s);
   __syncthreads();
   if (wave == 0)
     p.agents[((int64_t)bh * p.P + i) * D + lane] =
@@ -131,11 +159,13 @@ __global__ __launch_bounds__(256) void agent_pool_kernel(Params p) {
 
 // forward 1: per-chunk partial of V_agent = softmax((A*scale) K^T) V: chunk max, chunk row sum and
 // the un-normalised sum over the chunk's keys.
-__global__ __launch_bounds__(CH) void agent_s1_partial_kernel(Params p) {
-  __shared__ __attribute__((aligned(16))) float As[MAXP * D];
-  __shared__ float S[MAXP * CH];
-  __shared__ float red[4 * MAXP * D];
-  __shared__ float mloc[MAXP], lloc[MAXP];
+template <int PM>
+__global__ __launch_bounds__(NT) void agent_s1_partial_kernel(Params p) {
+  __shared__ __attribute__((aligned(16))) float As[PM * D];
+  __shared__ __attribute__((aligned(16))) float tile[CH * TS];   // k rows, then the cross-wave reduction
+  __shared__ float S[PM * CH];
+  __shared__ float mloc[PM], lloc[PM];
+  float* red = tile;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Where w = where(p.H, p.NC);
@@ -143,45 +173,55 @@ __global__ __launch_bounds__(CH) void agent_s1_partial_kernel(Params p) {
   const float* kb = p.k + (int64_t)w.b * p.ks.sb + (int64_t)w.h * p.ks.sh;
   const float* vb = p.v + (int64_t)w.b * p.vs.sb + (int64_t)w.h * p.vs.sh;
 
-  for (int i = wave; i < P; i += 4) As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane];
+  for (int i = wave; i < P; i += 4) As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane] * p.scale;
+  stage_rows(tile, kb, p.ks.st, t0, T, tid);
   __syncthreads();
-  {  // phase A: thread <-> key
-    const int t = t0 + tid;
-    float kr[D];
-    load_row(kb + (int64_t)t * p.ks.st, t < T, kr);
-    for (int i = 0; i < P; ++i) {
-      float a_s = 0.f;
+  {  // phase A: two threads per key
+    const int tok = tid >> 1, half = tid & 1;
+    float kr[HALF];
+    load_half(tile, tok, half, kr);
 #pragma unroll
-      for (int c4 = 0; c4 < D / 4; ++c4) {
-        const float4 a = ld4(&As[i * D + 4 * c4]);
-        a_s += (a.x * p.scale) * kr[4 * c4] + (a.y * p.scale) * kr[4 * c4 + 1] + (a.z * p.scale) * kr[4 * c4 + 2] +
-               (a.w * p.scale) * kr[4 * c4 + 3];
+    for (int i = 0; i < PM; ++i) {
+      if (i < P) {
+        const float s = dot_half(kr, &As[i * D], half);
+        if (half == 0) S[i * CH + tok] = (t0 + tok < T) ? s : -INFINITY;
       }
-      S[i * CH + tid] = (t < T) ? a_s : -INFINITY;
     }
   }
   __syncthreads();
   for (int i = wave; i < P; i += 4) {  // chunk max per agent: one wave per agent
-    float m = fmaxf(fmaxf(S[i * CH + lane], S[i * CH + 64 + lane]), fmaxf(S[i * CH + 128 + lane], S[i * CH + 192 + lane]));
+    float m = fmaxf(S[i * CH + lane], S[i * CH + 64 + lane]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) mloc[i] = m;  // finite: every chunk holds at least one key
   }
   __syncthreads();
-  for (int i = 0; i < P; ++i) S[i * CH + tid] = expf(S[i * CH + tid] - mloc[i]);
+  for (int e = tid; e < P * CH; e += NT) S[e] = expf(S[e] - mloc[e / CH]);
   __syncthreads();
-  {  // phase B: lane <-> channel, this wave's 64 keys
-    float acc[MAXP];
+  {  // phase B: 16 lanes per value row, 16 rows of the chunk per pass
+    const int sub = tid >> 4, c4 = (tid & 15) * 4;
+    float4 acc[PM];
 #pragma unroll
-    for (int i = 0; i < MAXP; ++i) acc[i] = 0.f;
-    const int tend = min(64, T - (t0 + 64 * wave));
-    for (int tt = 0; tt < tend; ++tt) {
-      const float vv = vb[(int64_t)(t0 + 64 * wave + tt) * p.vs.st + lane];
-      for (int i = 0; i < P; ++i) acc[i] += S[i * CH + 64 * wave + tt] * vv;
+    for (int i = 0; i < PM; ++i) acc[i] = f4(0.f);
+#pragma unroll 2
+    for (int r0 = 0; r0 < CH; r0 += NT / 16) {
+      const int r = r0 + sub;
+      if (t0 + r < T) {
+        const float4 vv = ld4(vb + (int64_t)(t0 + r) * p.vs.st + c4);
+#pragma unroll
+        for (int i = 0; i < PM; ++i)
+          if (i < P) fma4(acc[i], S[i * CH + r], vv);
+      }
     }
-    for (int i = 0; i < P; ++i) red[(wave * MAXP + i) * D + lane] = acc[i];
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+      if (i < P) {
+        const float4 a = fold_subs(acc[i]);
+        if (lane < 16) st4(&red[(wave * MAXP + i) * D + c4], a);
+      }
+    }
     for (int i = wave; i < P; i += 4) {  // row sums of this chunk, one wave per agent
-      float s = S[i * CH + lane] + S[i * CH + 64 + lane] + S[i * CH + 128 + lane] + S[i * CH + 192 + lane];
+      float s = S[i * CH + lane] + S[i * CH + 64 + lane];
 #pragma unroll
       for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
       if (lane == 0) lloc[i] = s;
@@ -196,20 +236,34 @@ __global__ __launch_bounds__(CH) void agent_s1_partial_kernel(Params p) {
 }
 
 // forward 2: fold the chunk partials (fixed chunk order): V_agent and the (max, sum) stats.
-// One workgroup per (b, h).
+// One workgroup per (b, h), one wave per agent.  The chunk stats sit one per lane (64 chunks per
+// pass) so their loads and exponentials are independent instead of a serial chain.
 __global__ __launch_bounds__(256) void agent_s1_combine_kernel(Params p) {
+  __shared__ float a_s[4][64], l_s[4][64];  // per wave: rescale factor and row sum of 64 chunks
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int64_t bh = blockIdx.x;
   for (int i = wave; i < p.P; i += 4) {
     const float* rec0 = p.part + (bh * p.NC * p.P + i) * PSTR;
+    const int64_t cstr = (int64_t)p.P * PSTR;
     float M = -INFINITY;
-    for (int c = 0; c < p.NC; ++c) M = fmaxf(M, rec0[(int64_t)c * p.P * PSTR + D]);
+    for (int c = lane; c < p.NC; c += 64) M = fmaxf(M, rec0[c * cstr + D]);
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
     float L = 0.f, s = 0.f;
-    for (int c = 0; c < p.NC; ++c) {
-      const float* rec = rec0 + (int64_t)c * p.P * PSTR;
-      const float a = expf(rec[D] - M);
-      L += a * rec[D + 1];
-      s += a * rec[lane];
+    for (int c0 = 0; c0 < p.NC; c0 += 64) {
+      const int cmine = c0 + lane;
+      a_s[wave][lane] = cmine < p.NC ? expf(rec0[cmine * cstr + D] - M) : 0.f;
+      l_s[wave][lane] = cmine < p.NC ? rec0[cmine * cstr + D + 1] : 0.f;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int n = min(64, p.NC - c0);
+#pragma unroll 4
+      for (int c = 0; c < n; ++c) {  // ascending chunk order; a wave reads only what it wrote
+        const float a = a_s[wave][c];
+        L += a * l_s[wave][c];
+        s += a * rec0[(c0 + c) * cstr + lane];
+      }
+      __builtin_amdgcn_wave_barrier();
     }
     const int64_t row = bh * p.P + i;
     p.vagent[row * D + lane] = s / L;
@@ -217,49 +271,84 @@ __global__ __launch_bounds__(256) void agent_s1_combine_kernel(Params p) {
   }
 }
 
+// depthwise 3x3 over the (head, token) plane at (hh, t), channels c4..c4+3, zero padded.
+// wq[j] holds weight tap j of the four channels.  FLIP: transposed convolution (backward).
+template <bool FLIP>
+__device__ __forceinline__ void conv4(float4& acc, const float* xb, const Strides& xs, int H, int T, int hh, int t, int c4,
+                                      const float4 (&wq)[9]) {
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    const int h2 = FLIP ? hh - (a - 1) : hh + (a - 1);
+    if (h2 < 0 || h2 >= H) continue;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const int t2 = FLIP ? t - (b - 1) : t + (b - 1);
+      if (t2 < 0 || t2 >= T) continue;
+      mad4(acc, wq[a * 3 + b], ld4(xb + (int64_t)h2 * xs.sh + (int64_t)t2 * xs.st + c4));
+    }
+  }
+}
+__device__ __forceinline__ void load_taps(const float* convw, int c4, float4 (&wq)[9]) {
+#pragma unroll
+  for (int j = 0; j < 9; ++j)
+    wq[j] = make_float4(convw[(c4 + 0) * 9 + j], convw[(c4 + 1) * 9 + j], convw[(c4 + 2) * 9 + j], convw[(c4 + 3) * 9 + j]);
+}
+
 // forward 3: O = softmax((q*scale) A^T) V_agent + dwc(v) for one chunk of tokens.
-__global__ __launch_bounds__(CH) void agent_s2_kernel(Params p) {
-  __shared__ __attribute__((aligned(16))) float As[MAXP * D];
-  __shared__ float S[MAXP * CH];
+template <int PM>
+__global__ __launch_bounds__(NT) void agent_s2_kernel(Params p) {
+  __shared__ __attribute__((aligned(16))) float As[PM * D];
+  __shared__ __attribute__((aligned(16))) float tile[CH * TS];   // q rows
+  __shared__ float S[PM * CH];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Where w = where(p.H, p.NC);
   const int P = p.P, T = p.T, t0 = w.t0;
   const float* qb = p.q + (int64_t)w.b * p.qs.sb + (int64_t)w.h * p.qs.sh;
 
-  for (int i = wave; i < P; i += 4) As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane];
-  float w9[9];
-#pragma unroll
-  for (int j = 0; j < 9; ++j) w9[j] = p.convw[lane * 9 + j];
-  const float cb = p.convb[lane];
-  float var[MAXP];
-#pragma unroll
-  for (int i = 0; i < MAXP; ++i) var[i] = (i < P) ? p.vagent[(w.bh * P + i) * D + lane] : 0.f;
+  for (int i = wave; i < P; i += 4) As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane] * p.scale;
+  stage_rows(tile, qb, p.qs.st, t0, T, tid);
   __syncthreads();
-  {  // phase A: thread <-> token: p scores, softmax over the agents
-    const int t = t0 + tid;
-    float qr[D];
-    load_row(qb + (int64_t)t * p.qs.st, t < T, qr);
-#pragma unroll
-    for (int c = 0; c < D; ++c) qr[c] *= p.scale;
-    float sc[MAXP];
+  {  // phase A: two threads per token: p scores, softmax over the agents
+    const int tok = tid >> 1, half = tid & 1;
+    float qr[HALF];
+    load_half(tile, tok, half, qr);
+    float sc[PM];
     float m = -INFINITY;
-    for (int i = 0; i < P; ++i) { sc[i] = dot_row(qr, &As[i * D]); m = fmaxf(m, sc[i]); }
+#pragma unroll
+    for (int i = 0; i < PM; ++i)
+      if (i < P) { sc[i] = dot_half(qr, &As[i * D], half); m = fmaxf(m, sc[i]); }
     float l = 0.f;
-    for (int i = 0; i < P; ++i) { sc[i] = expf(sc[i] - m); l += sc[i]; }
-    for (int i = 0; i < P; ++i) S[i * CH + tid] = sc[i] / l;
+#pragma unroll
+    for (int i = 0; i < PM; ++i)
+      if (i < P) { sc[i] = expf(sc[i] - m); l += sc[i]; }
+    if (half == 0) {
+#pragma unroll
+      for (int i = 0; i < PM; ++i)
+        if (i < P) S[i * CH + tok] = sc[i] / l;
+    }
   }
   __syncthreads();
-  {  // phase B: lane <-> channel
+  {  // phase B: 16 lanes per output row
+    const int sub = tid >> 4, c4 = (tid & 15) * 4;
+    float4 wq[9], var[PM];
+    load_taps(p.convw, c4, wq);
+    const float4 cb = ld4(p.convb + c4);
+#pragma unroll
+    for (int i = 0; i < PM; ++i) var[i] = (i < P) ? ld4(p.vagent + (w.bh * P + i) * D + c4) : f4(0.f);
     const float* vbatch = p.v + (int64_t)w.b * p.vs.sb;
     float* ob = p.o + (int64_t)w.b * p.os.sb + (int64_t)w.h * p.os.sh;
-    const int tend = min(64, T - (t0 + 64 * wave));
-    for (int tt = 0; tt < tend; ++tt) {
-      const int t = t0 + 64 * wave + tt;
-      float o = 0.f;
-      for (int i = 0; i < P; ++i) o += S[i * CH + 64 * wave + tt] * var[i];
-      o += conv_at(vbatch, p.vs, p.H, T, w.h, t, lane, w9, cb);
-      ob[(int64_t)t * p.os.st + lane] = o;
+#pragma unroll 2
+    for (int r0 = 0; r0 < CH; r0 += NT / 16) {
+      const int r = r0 + sub, t = t0 + r;
+      if (t < T) {
+        float4 o = cb;
+        conv4<false>(o, vbatch, p.vs, p.H, T, w.h, t, c4, wq);
+#pragma unroll
+        for (int i = 0; i < PM; ++i)
+          if (i < P) fma4(o, S[i * CH + r], var[i]);
+        st4(ob + (int64_t)t * p.os.st + c4, o);
+      }
     }
   }
 }
@@ -267,12 +356,14 @@ __global__ __launch_bounds__(CH) void agent_s2_kernel(Params p) {
 // ---------------------------------------------------------------------------------------
 // backward 0: stage-2 backward of one chunk: dq (broadcast part), partials of dV_agent, of dA
 // (broadcast part) and of the conv weight / bias gradients.
-__global__ __launch_bounds__(CH) void agent_s2_bwd_kernel(BwdParams p) {
-  __shared__ __attribute__((aligned(16))) float As[MAXP * D];
-  __shared__ __attribute__((aligned(16))) float Vas[MAXP * D];
-  __shared__ float S[MAXP * CH];    // P2 of the chunk
-  __shared__ float DS[MAXP * CH];   // dS2 of the chunk
-  __shared__ float red[4 * MAXP * D];
+template <int PM>
+__global__ __launch_bounds__(NT) void agent_s2_bwd_kernel(BwdParams p) {
+  __shared__ __attribute__((aligned(16))) float As[PM * D];
+  __shared__ __attribute__((aligned(16))) float Vas[PM * D];
+  __shared__ __attribute__((aligned(16))) float tile[CH * TS];   // q rows, dO rows, dq rows out, reductions
+  __shared__ float S[PM * CH];    // P2 of the chunk
+  __shared__ float DS[PM * CH];   // dS2 of the chunk
+  float* red = tile;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Where w = where(p.H, p.NC);
@@ -286,84 +377,130 @@ __global__ __launch_bounds__(CH) void agent_s2_bwd_kernel(BwdParams p) {
     As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane];
     Vas[i * D + lane] = p.vagent[(w.bh * P + i) * D + lane];
   }
+  stage_rows(tile, qb, p.qs.st, t0, T, tid);
   __syncthreads();
-  {  // phase A: thread <-> token
-    const int t = t0 + tid;
-    const bool ok = t < T;
-    float qr[D], gr[D];
-    load_row(qb + (int64_t)t * p.qs.st, ok, qr);
-    load_row(gb + (int64_t)t * p.dos.st, ok, gr);
-    float sc[MAXP], dp[MAXP];
-    float m = -INFINITY;
-    for (int i = 0; i < P; ++i) {
-      sc[i] = dot_row(qr, &As[i * D]) * p.scale;
-      dp[i] = dot_row(gr, &Vas[i * D]);
-      m = fmaxf(m, sc[i]);
-    }
-    float l = 0.f;
-    for (int i = 0; i < P; ++i) { sc[i] = expf(sc[i] - m); l += sc[i]; }
-    float dl = 0.f;
-    for (int i = 0; i < P; ++i) { sc[i] /= l; dl += sc[i] * dp[i]; }
-    for (int i = 0; i < P; ++i) {
-      const float ds = sc[i] * (dp[i] - dl);
-      S[i * CH + tid] = ok ? sc[i] : 0.f;
-      DS[i * CH + tid] = ok ? ds : 0.f;
-      dp[i] = ds;
-    }
-    if (ok) {  // dq_t = scale * sum_i dS2[t,i] A_i   (row-per-lane store)
-      float* dst = dqb + (int64_t)t * p.dqs.st;
+  {  // phase A: two threads per token
+    const int tok = tid >> 1, half = tid & 1;
+    const bool ok = t0 + tok < T;
+    float sc[PM], dp[PM];
+    {
+      float qr[HALF];
+      load_half(tile, tok, half, qr);
 #pragma unroll
-      for (int c4 = 0; c4 < D / 4; ++c4) {
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < P; ++i) {
-          const float4 a = ld4(&As[i * D + 4 * c4]);
-          o.x += dp[i] * a.x; o.y += dp[i] * a.y; o.z += dp[i] * a.z; o.w += dp[i] * a.w;
+      for (int i = 0; i < PM; ++i)
+        if (i < P) sc[i] = dot_half(qr, &As[i * D], half) * p.scale;
+    }
+    __syncthreads();
+    stage_rows(tile, gb, p.dos.st, t0, T, tid);
+    __syncthreads();
+    {
+      float gr[HALF];
+      load_half(tile, tok, half, gr);
+#pragma unroll
+      for (int i = 0; i < PM; ++i)
+        if (i < P) dp[i] = dot_half(gr, &Vas[i * D], half);
+    }
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PM; ++i)
+      if (i < P) m = fmaxf(m, sc[i]);
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < PM; ++i)
+      if (i < P) { sc[i] = expf(sc[i] - m); l += sc[i]; }
+    float dl = 0.f;
+#pragma unroll
+    for (int i = 0; i < PM; ++i)
+      if (i < P) { sc[i] /= l; dl += sc[i] * dp[i]; }
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+      if (i < P) {
+        const float ds = sc[i] * (dp[i] - dl);
+        if (half == 0) {
+          S[i * CH + tok] = ok ? sc[i] : 0.f;
+          DS[i * CH + tok] = ok ? ds : 0.f;
         }
-        st4(dst + 4 * c4, make_float4(o.x * p.scale, o.y * p.scale, o.z * p.scale, o.w * p.scale));
+        dp[i] = ds * p.scale;
       }
+    }
+    // dq_t = scale * sum_i dS2[t,i] A_i: this thread's 32 channels into its own half row of the tile
+    float* dst = tile + tok * TS + HALF * half;
+#pragma unroll
+    for (int j = 0; j < HALF / 4; ++j) {
+      float4 o = f4(0.f);
+#pragma unroll
+      for (int i = 0; i < PM; ++i)
+        if (i < P) fma4(o, dp[i], ld4(&As[i * D + HALF * half + 4 * j]));
+      st4(dst + 4 * j, o);
     }
   }
   __syncthreads();
-  float accva[MAXP], acca[MAXP], dw9[9], dbs = 0.f;
+  unstage_rows(tile, dqb, p.dqs.st, t0, T, tid);
+  const int sub = tid >> 4, c4 = (tid & 15) * 4;
+  float4 accva[PM], acca[PM], dw9[9], dbs = f4(0.f);
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) { accva[i] = 0.f; acca[i] = 0.f; }
+  for (int i = 0; i < PM; ++i) { accva[i] = f4(0.f); acca[i] = f4(0.f); }
 #pragma unroll
-  for (int j = 0; j < 9; ++j) dw9[j] = 0.f;
-  {  // phase B: lane <-> channel
-    const int tend = min(64, T - (t0 + 64 * wave));
-    for (int tt = 0; tt < tend; ++tt) {
-      const int t = t0 + 64 * wave + tt;
-      const float g = gb[(int64_t)t * p.dos.st + lane];
-      const float qv = qb[(int64_t)t * p.qs.st + lane];
-      for (int i = 0; i < P; ++i) {
-        accva[i] += S[i * CH + 64 * wave + tt] * g;
-        acca[i] += DS[i * CH + 64 * wave + tt] * qv;
-      }
-      dbs += g;
+  for (int j = 0; j < 9; ++j) dw9[j] = f4(0.f);
+  {  // phase B: 16 lanes per row
+    for (int r0 = 0; r0 < CH; r0 += NT / 16) {
+      const int r = r0 + sub, t = t0 + r;
+      if (t < T) {
+        const float4 g = ld4(gb + (int64_t)t * p.dos.st + c4);
+        const float4 qv = ld4(qb + (int64_t)t * p.qs.st + c4);
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int h2 = h + a - 1;
-        if (h2 < 0 || h2 >= p.H) continue;
+        for (int i = 0; i < PM; ++i) {
+          if (i < P) {
+            fma4(accva[i], S[i * CH + r], g);
+            fma4(acca[i], DS[i * CH + r], qv);
+          }
+        }
+        dbs.x += g.x; dbs.y += g.y; dbs.z += g.z; dbs.w += g.w;
 #pragma unroll
-        for (int bb = 0; bb < 3; ++bb) {
-          const int t2 = t + bb - 1;
-          if (t2 < 0 || t2 >= T) continue;
-          dw9[a * 3 + bb] += g * vbatch[(int64_t)h2 * p.vs.sh + (int64_t)t2 * p.vs.st + lane];
+        for (int a = 0; a < 3; ++a) {
+          const int h2 = h + a - 1;
+          if (h2 < 0 || h2 >= p.H) continue;
+#pragma unroll
+          for (int bb = 0; bb < 3; ++bb) {
+            const int t2 = t + bb - 1;
+            if (t2 < 0 || t2 >= T) continue;
+            mad4(dw9[a * 3 + bb], g, ld4(vbatch + (int64_t)h2 * p.vs.sh + (int64_t)t2 * p.vs.st + c4));
+          }
         }
       }
     }
   }
   const int64_t cell = w.bh * p.NC + w.ch;
-  for (int i = 0; i < P; ++i) red[(wave * MAXP + i) * D + lane] = accva[i];
+  __syncthreads();  // the dq rows have left the tile
+#pragma unroll
+  for (int i = 0; i < PM; ++i) {
+    if (i < P) {
+      const float4 a = fold_subs(accva[i]);
+      if (lane < 16) st4(&red[(wave * MAXP + i) * D + c4], a);
+    }
+  }
   __syncthreads();
   for (int i = wave; i < P; i += 4) p.pva[(cell * P + i) * D + lane] = fold4(red, i, lane);
   __syncthreads();
-  for (int i = 0; i < P; ++i) red[(wave * MAXP + i) * D + lane] = acca[i];
+#pragma unroll
+  for (int i = 0; i < PM; ++i) {
+    if (i < P) {
+      const float4 a = fold_subs(acca[i]);
+      if (lane < 16) st4(&red[(wave * MAXP + i) * D + c4], a);
+    }
+  }
   __syncthreads();
   for (int i = wave; i < P; i += 4) p.pa2[(cell * P + i) * D + lane] = p.scale * fold4(red, i, lane);
   __syncthreads();
-  for (int j = 0; j < 9; ++j) red[(wave * MAXP + j) * D + lane] = dw9[j];
-  red[(wave * MAXP + 9) * D + lane] = dbs;
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const float4 a = fold_subs(dw9[j]);
+    if (lane < 16) st4(&red[(wave * MAXP + j) * D + c4], a);
+  }
+  {
+    const float4 a = fold_subs(dbs);
+    if (lane < 16) st4(&red[(wave * MAXP + 9) * D + c4], a);
+  }
   __syncthreads();
   if (wave == 0) {
     for (int j = 0; j < 9; ++j) p.dconvw_part[(cell * 9 + j) * D + lane] = fold4(red, j, lane);
@@ -378,6 +515,7 @@ __global__ __launch_bounds__(256) void agent_mid_kernel(BwdParams p) {
   const int64_t bh = blockIdx.x;
   for (int i = wave; i < p.P; i += 4) {
     float sva = 0.f, sa2 = 0.f;
+#pragma unroll 4
     for (int c = 0; c < p.NC; ++c) {
       const int64_t o = (((bh * p.NC + c) * p.P) + i) * D + lane;
       sva += p.pva[o];
@@ -395,13 +533,15 @@ __global__ __launch_bounds__(256) void agent_mid_kernel(BwdParams p) {
 
 // backward 2: stage-1 backward of one chunk: dk, dv (aggregation + transposed conv of dO), partial
 // of dA (aggregation part).
-__global__ __launch_bounds__(CH) void agent_s1_bwd_kernel(BwdParams p) {
-  __shared__ __attribute__((aligned(16))) float As[MAXP * D];
-  __shared__ __attribute__((aligned(16))) float dVas[MAXP * D];
-  __shared__ float S[MAXP * CH];    // P1 of the chunk
-  __shared__ float DS[MAXP * CH];   // dS1 of the chunk
-  __shared__ float red[4 * MAXP * D];
-  __shared__ float m1[MAXP], l1[MAXP], delta1[MAXP];
+template <int PM>
+__global__ __launch_bounds__(NT) void agent_s1_bwd_kernel(BwdParams p) {
+  __shared__ __attribute__((aligned(16))) float As[PM * D];
+  __shared__ __attribute__((aligned(16))) float dVas[PM * D];
+  __shared__ __attribute__((aligned(16))) float tile[CH * TS];   // k rows, v rows, dk rows out, reduction
+  __shared__ float S[PM * CH];    // P1 of the chunk
+  __shared__ float DS[PM * CH];   // dS1 of the chunk
+  __shared__ float m1[PM], l1[PM], delta1[PM];
+  float* red = tile;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const Where w = where(p.H, p.NC);
@@ -418,94 +558,128 @@ __global__ __launch_bounds__(CH) void agent_s1_bwd_kernel(BwdParams p) {
     dVas[i * D + lane] = p.dva[row * D + lane];
     if (lane == 0) { m1[i] = p.stats1[row * 2]; l1[i] = p.stats1[row * 2 + 1]; delta1[i] = p.delta1[row]; }
   }
-  float w9[9];
-#pragma unroll
-  for (int j = 0; j < 9; ++j) w9[j] = p.convw[lane * 9 + j];
+  stage_rows(tile, kb, p.ks.st, t0, T, tid);
   __syncthreads();
-  {  // phase A: thread <-> key
-    const int t = t0 + tid;
-    const bool ok = t < T;
-    float kr[D], vr[D];
-    load_row(kb + (int64_t)t * p.ks.st, ok, kr);
-    load_row(vb + (int64_t)t * p.vs.st, ok, vr);
-    float ds[MAXP];
-    for (int i = 0; i < P; ++i) {
-      const float s1 = dot_row(kr, &As[i * D]) * p.scale;
-      const float pr = expf(s1 - m1[i]) / l1[i];
-      const float dp = dot_row(vr, &dVas[i * D]);
-      ds[i] = pr * (dp - delta1[i]);
-      S[i * CH + tid] = ok ? pr : 0.f;
-      DS[i * CH + tid] = ok ? ds[i] : 0.f;
-    }
-    if (ok) {  // dk_t = scale * sum_i dS1[i,t] A_i
-      float* dst = dkb + (int64_t)t * p.dks.st;
+  {  // phase A: two threads per key
+    const int tok = tid >> 1, half = tid & 1;
+    const bool ok = t0 + tok < T;
+    float pr[PM], ds[PM];
+    {
+      float kr[HALF];
+      load_half(tile, tok, half, kr);
 #pragma unroll
-      for (int c4 = 0; c4 < D / 4; ++c4) {
-        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int i = 0; i < P; ++i) {
-          const float4 a = ld4(&As[i * D + 4 * c4]);
-          o.x += ds[i] * a.x; o.y += ds[i] * a.y; o.z += ds[i] * a.z; o.w += ds[i] * a.w;
+      for (int i = 0; i < PM; ++i)
+        if (i < P) pr[i] = expf(dot_half(kr, &As[i * D], half) * p.scale - m1[i]) / l1[i];
+    }
+    __syncthreads();
+    stage_rows(tile, vb, p.vs.st, t0, T, tid);
+    __syncthreads();
+    {
+      float vr[HALF];
+      load_half(tile, tok, half, vr);
+#pragma unroll
+      for (int i = 0; i < PM; ++i) {
+        if (i < P) {
+          const float dp = dot_half(vr, &dVas[i * D], half);
+          const float d = pr[i] * (dp - delta1[i]);
+          if (half == 0) {
+            S[i * CH + tok] = ok ? pr[i] : 0.f;
+            DS[i * CH + tok] = ok ? d : 0.f;
+          }
+          ds[i] = d * p.scale;
         }
-        st4(dst + 4 * c4, make_float4(o.x * p.scale, o.y * p.scale, o.z * p.scale, o.w * p.scale));
       }
+    }
+    // dk_t = scale * sum_i dS1[i,t] A_i
+    float* dst = tile + tok * TS + HALF * half;
+#pragma unroll
+    for (int j = 0; j < HALF / 4; ++j) {
+      float4 o = f4(0.f);
+#pragma unroll
+      for (int i = 0; i < PM; ++i)
+        if (i < P) fma4(o, ds[i], ld4(&As[i * D + HALF * half + 4 * j]));
+      st4(dst + 4 * j, o);
     }
   }
   __syncthreads();
-  float acca[MAXP], dva[MAXP];
+  unstage_rows(tile, dkb, p.dks.st, t0, T, tid);
+  const int sub = tid >> 4, c4 = (tid & 15) * 4;
+  float4 acca[PM];
+  {  // phase B: 16 lanes per row
+    float4 wq[9], dva[PM];
+    load_taps(p.convw, c4, wq);
 #pragma unroll
-  for (int i = 0; i < MAXP; ++i) { acca[i] = 0.f; dva[i] = (i < P) ? dVas[i * D + lane] : 0.f; }
-  {  // phase B: lane <-> channel
-    const int tend = min(64, T - (t0 + 64 * wave));
-    for (int tt = 0; tt < tend; ++tt) {
-      const int t = t0 + 64 * wave + tt;
-      const float kv = kb[(int64_t)t * p.ks.st + lane];
-      float dvv = 0.f;
-      for (int i = 0; i < P; ++i) {
-        acca[i] += DS[i * CH + 64 * wave + tt] * kv;
-        dvv += S[i * CH + 64 * wave + tt] * dva[i];
-      }
-      // transposed depthwise conv: dv[h,t] += sum w[a][b] * dO[h-(a-1), t-(b-1)]
+    for (int i = 0; i < PM; ++i) { acca[i] = f4(0.f); dva[i] = (i < P) ? ld4(&dVas[i * D + c4]) : f4(0.f); }
+#pragma unroll 2
+    for (int r0 = 0; r0 < CH; r0 += NT / 16) {
+      const int r = r0 + sub, t = t0 + r;
+      if (t < T) {
+        const float4 kv = ld4(kb + (int64_t)t * p.ks.st + c4);
+        float4 dvv = f4(0.f);
+        // transposed depthwise conv: dv[h,t] += sum w[a][b] * dO[h-(a-1), t-(b-1)]
+        conv4<true>(dvv, gbatch, p.dos, p.H, T, h, t, c4, wq);
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const int h2 = h - (a - 1);
-        if (h2 < 0 || h2 >= p.H) continue;
-#pragma unroll
-        for (int bb = 0; bb < 3; ++bb) {
-          const int t2 = t - (bb - 1);
-          if (t2 < 0 || t2 >= T) continue;
-          dvv += w9[a * 3 + bb] * gbatch[(int64_t)h2 * p.dos.sh + (int64_t)t2 * p.dos.st + lane];
+        for (int i = 0; i < PM; ++i) {
+          if (i < P) {
+            fma4(acca[i], DS[i * CH + r], kv);
+            fma4(dvv, S[i * CH + r], dva[i]);
+          }
         }
+        st4(dvb + (int64_t)t * p.dvs.st + c4, dvv);
       }
-      dvb[(int64_t)t * p.dvs.st + lane] = dvv;
     }
   }
-  for (int i = 0; i < P; ++i) red[(wave * MAXP + i) * D + lane] = acca[i];
+  __syncthreads();  // the dk rows have left the tile
+#pragma unroll
+  for (int i = 0; i < PM; ++i) {
+    if (i < P) {
+      const float4 a = fold_subs(acca[i]);
+      if (lane < 16) st4(&red[(wave * MAXP + i) * D + c4], a);
+    }
+  }
   __syncthreads();
   const int64_t cell = w.bh * p.NC + w.ch;
   for (int i = wave; i < P; i += 4) p.pa1[(cell * P + i) * D + lane] = p.scale * fold4(red, i, lane);
 }
 
 // backward 3: dq[b,h,t,:] += sum over the bins i containing t of dA[b,h,i,:] / len(bin i), with
-// dA = dA(stage 2) + the chunk partials of dA(stage 1) folded in chunk order.
-__global__ __launch_bounds__(256) void agent_pool_bwd_kernel(BwdParams p) {
-  const int64_t idx = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b,h,t)
-  const int c = threadIdx.x & 63;
+// dA = dA(stage 2) + the chunk partials of dA(stage 1) folded in chunk order.  One workgroup per
+// (b, h, 64-token block): dA / len of the bins that meet the block is rebuilt in LDS first.
+constexpr int PB = 64;
+__global__ __launch_bounds__(NT) void agent_pool_bwd_kernel(BwdParams p) {
+  __shared__ __attribute__((aligned(16))) float dA[MAXP * D];
+  __shared__ int lo_s[MAXP], hi_s[MAXP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int T = p.T, P = p.P;
-  if (idx >= (int64_t)p.B * p.H * T) return;
-  const int t = (int)(idx % T);
-  const int64_t bh = idx / T;
+  const int nblk = (T + PB - 1) / PB;
+  const int blk = blockIdx.x % nblk;
+  const int64_t bh = blockIdx.x / nblk;
   const int h = (int)(bh % p.H), b = (int)(bh / p.H);
-  float add = 0.f;
-  for (int i = 0; i < P; ++i) {
+  const int t0 = blk * PB, t1 = min(T, t0 + PB);
+  for (int i = wave; i < P; i += 4) {
     const int lo = bin_lo(i, T, P), hi = bin_hi(i, T, P);
-    if (t >= lo && t < hi) {
-      float da = p.da2[(bh * P + i) * D + c];
-      for (int ch = 0; ch < p.NC; ++ch) da += p.pa1[(((bh * p.NC + ch) * P) + i) * D + c];
-      add += da / (float)(hi - lo);
+    if (lane == 0) { lo_s[i] = lo; hi_s[i] = hi; }
+    if (lo < t1 && hi > t0) {
+      float da = p.da2[(bh * P + i) * D + lane];
+      for (int ch = 0; ch < p.NC; ++ch) da += p.pa1[(((bh * p.NC + ch) * P) + i) * D + lane];
+      dA[i * D + lane] = da / (float)(hi - lo);
     }
   }
-  float* dst = p.dq + (int64_t)b * p.dqs.sb + (int64_t)h * p.dqs.sh + (int64_t)t * p.dqs.st + c;
-  *dst += add;
+  __syncthreads();
+  const int c4 = (tid & 15) * 4;
+  float* dqb = p.dq + (int64_t)b * p.dqs.sb + (int64_t)h * p.dqs.sh;
+#pragma unroll
+  for (int r0 = 0; r0 < PB; r0 += NT / 16) {
+    const int t = t0 + r0 + (tid >> 4);
+    if (t < T) {
+      float4 add = f4(0.f);
+      for (int i = 0; i < P; ++i)
+        if (t >= lo_s[i] && t < hi_s[i]) fma4(add, 1.f, ld4(&dA[i * D + c4]));
+      float* dst = dqb + (int64_t)t * p.dqs.st + c4;
+      const float4 cur = ld4(dst);
+      st4(dst, make_float4(cur.x + add.x, cur.y + add.y, cur.z + add.z, cur.w + add.w));
+    }
+  }
 }
 
 }  // namespace amk_agent
@@ -515,6 +689,13 @@ using namespace amk_agent;
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool sok(const Strides& s) { return s.sb % 4 == 0 && s.st % 4 == 0 && s.sh % 4 == 0; }
 static int nchunks(int T) { return (T + CH - 1) / CH; }
+
+// kernels are instantiated for up to 8 and up to 16 agents per head (register arrays sized to that)
+#define AMK_AGENT_LAUNCH(KERNEL, P_, ...)                                    \
+  do {                                                                       \
+    if ((P_) <= 8) hipLaunchKernelGGL(KERNEL<8>, __VA_ARGS__);               \
+    else hipLaunchKernelGGL(KERNEL<16>, __VA_ARGS__);                        \
+  } while (0)
 
 extern "C" int amk_agent_num_chunks(int T) { return T > 0 ? nchunks(T) : 0; }
 
@@ -545,10 +726,10 @@ extern "C" int amk_agent_attn_fwd(const float* q, const float* k, const float* v
   const int64_t cells = (int64_t)B * H * p.NC;
   AMK_CHECK_SUPPORTED(cells * P < (1ll << 31), "amk_agent_attn_fwd: B*h*chunks*p exceeds the grid limit");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(agent_pool_kernel, dim3((unsigned)(B * H * P)), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(agent_s1_partial_kernel, dim3((unsigned)cells), dim3(CH), 0, st, p);
+  hipLaunchKernelGGL(agent_pool_kernel, dim3((unsigned)(B * H * P)), dim3(NT), 0, st, p);
+  AMK_AGENT_LAUNCH(agent_s1_partial_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
   hipLaunchKernelGGL(agent_s1_combine_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(agent_s2_kernel, dim3((unsigned)cells), dim3(CH), 0, st, p);
+  AMK_AGENT_LAUNCH(agent_s2_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
   AMK_CHECK_LAUNCH("amk_agent_attn_fwd");
   return AMK_OK;
 }
@@ -578,13 +759,13 @@ extern "C" int amk_agent_attn_bwd(const float* q, const float* k, const float* v
   AMK_CHECK_ARG(a16(q) && a16(k) && a16(v) && a16(d_o) && a16(dq) && a16(dk) && a16(dv) && sok(p.qs) && sok(p.ks) &&
                     sok(p.vs) && sok(p.dos) && sok(p.dqs) && sok(p.dks) && sok(p.dvs),
                 "amk_agent_attn_bwd: pointers must be 16-byte aligned and strides multiples of 4");
-  const int64_t tok = (int64_t)B * H * T;
-  AMK_CHECK_SUPPORTED((tok + 3) / 4 < (1ll << 31), "amk_agent_attn_bwd: B*h*T exceeds the grid limit");
+  const int64_t pblk = (int64_t)B * H * ((T + PB - 1) / PB);
+  AMK_CHECK_SUPPORTED(pblk < (1ll << 31), "amk_agent_attn_bwd: B*h*T exceeds the grid limit");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(agent_s2_bwd_kernel, dim3((unsigned)cells), dim3(CH), 0, st, p);
+  AMK_AGENT_LAUNCH(agent_s2_bwd_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
   hipLaunchKernelGGL(agent_mid_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, p);
-  hipLaunchKernelGGL(agent_s1_bwd_kernel, dim3((unsigned)cells), dim3(CH), 0, st, p);
-  hipLaunchKernelGGL(agent_pool_bwd_kernel, dim3((unsigned)((tok + 3) / 4)), dim3(256), 0, st, p);
+  AMK_AGENT_LAUNCH(agent_s1_bwd_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
+  hipLaunchKernelGGL(agent_pool_bwd_kernel, dim3((unsigned)pblk), dim3(NT), 0, st, p);
   AMK_CHECK_LAUNCH("amk_agent_attn_bwd");
   return AMK_OK;
 }

@@ -204,12 +204,12 @@ int amk_moe_gate_grad(const float* d_out, const float* Y, const int64_t* ids, co
  * q,k,v,o addressed like amk_attn_fwd (T rows).  Saved for the backward: agents (B,H,P,D),
  * vagent (B,H,P,D), stats1 (B,H,P,2) = {row max, row sum} of the aggregation softmax.
  * D must be 64, P <= 16, P <= T.
- * The sequence is processed in chunks of 256 tokens, one workgroup per (batch, head, chunk);
+ * The sequence is processed in chunks of 128 tokens, one workgroup per (batch, head, chunk);
  * sums over tokens go through per-chunk partials in the caller's workspace `ws`
  * (amk_agent_ws_floats(B,H,T,P,backward) floats, contents undefined on return) and are folded
  * in chunk order, so results are bitwise reproducible.
  * -------------------------------------------------------------------------- */
-int amk_agent_num_chunks(int T);                                  /* ceil(T / 256); 0 for T <= 0 */
+int amk_agent_num_chunks(int T);                                  /* ceil(T / 128); 0 for T <= 0 */
 int64_t amk_agent_ws_floats(int B, int H, int T, int P, int backward); /* workspace size in floats */
 
 int amk_agent_attn_fwd(const float* q, const float* k, const float* v, const float* conv_w, const float* conv_b,
