@@ -33,12 +33,14 @@ class _Bucket:
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, communicate_when_alone=False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradReducer: no trainable parameters")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # a world of one needs no collectives; communicate_when_alone=True issues them anyway (RCCL smoke test)
+        self.alone = self.world == 1 and not (communicate_when_alone and dist.is_initialized())
         dev = self.params[0].device
         self.on_gpu = dev.type == "cuda"
         self.side = torch.cuda.Stream(device=dev) if self.on_gpu else None
@@ -76,7 +78,7 @@ class GradReducer:
 
     def broadcast_parameters(self, src=0):
         """Make every rank start from rank `src`'s parameters (what DDP does at wrap time)."""
-        if self.world > 1:
+        if not self.alone:
             for p in self.params:
                 dist.broadcast(p.data, src=src, group=self.group)
 
@@ -105,7 +107,7 @@ class GradReducer:
 
     def _launch(self, b):
         b.launched = True
-        if self.world == 1:
+        if self.alone:
             return
         if self.on_gpu:
             ready = torch.cuda.Event()
@@ -124,7 +126,7 @@ class GradReducer:
         for b in self.buckets:
             if not b.launched:  # parameters without a gradient this step: zeros travel
                 self._launch(b)
-        if self.world == 1:
+        if self.alone:
             return
         if self.on_gpu:
             torch.cuda.current_stream().wait_stream(self.side)
