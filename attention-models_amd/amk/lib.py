@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libamk.so")
+LIB_PATH = os.environ.get("AMK_LIB") or os.path.join(_HERE, "libamk.so")  # AMK_LIB: A/B builds (tools/)
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, "..", "..", "include", "amk.h"))
 
 AMK_OK = 0

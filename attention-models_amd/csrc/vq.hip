@@ -9,12 +9,17 @@
 //        contiguous slice of the codebook.  Per 32-code tile:
 //          dot^T (32 codes x 32 rows) = en_tile (A operand, LDS rows, ds_read_b128)
 //                                       x zn^T  (B operand, C/2 registers, loaded once)
-//          dist = (zz + ee[code]) - 2*dot   -- the reference's three-term expression, same
-//                                              association, one FMA for the exact "2*dot"
-//          running (min, argmin) per lane with strict '<' over ascending codes = torch.argmin's
-//          first-minimum rule; the two half-waves of a row are merged at the end.
-//   vq_finalize      : merges the per-slice (min, idx) partials (lowest index wins ties), gathers
-//        E[idx], re-normalises, forms the straight-through output and the squared-error partials.
+//          argmin_k (zz + ee[k] - 2 dot[k]) = argmax_k (dot[k] - ee[k]/2): the accumulator starts
+//          at -ee/2 (read from LDS straight into the MFMA's C operand), so the score comes out of
+//          the matrix pipe with no VALU work.  Every VALU instruction is paid against the f32
+//          MFMA pipe (4 cycles each, measured: 1024 + 4*n cycles per tile), so the sweep only keeps
+//          a running max over GROUPS of 4 consecutive codes (max tree + cmp/max/select per group:
+//          22 instructions per tile instead of 86 for a per-code argmin) with strict '>' over
+//          ascending groups; the two half-waves of a row are merged at the end.
+//   vq_finalize      : merges the per-slice (max, group) partials (lowest group wins ties), ranks
+//        the 4 codes of the winning group (strict '>' ascending = torch.argmin's first-minimum
+//        rule), gathers E[idx], re-normalises, forms the straight-through output and the
+//        squared-error partials.
 //   vq_bwd           : straight-through + commitment gradient to z through the l2-norm Jacobian;
 //        codebook rows receive 2(zq - zn)/(N*C) through their own Jacobian by f32 atomics
 //        (one 128-B segment per row per wave-instruction: the full-rate shape).
@@ -95,10 +100,6 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
 #pragma unroll
     for (int s = 0; s < HC; ++s) zreg[s] = zreg[s] / denom;
   }
-  float zz = 0.f;
-#pragma unroll
-  for (int s = 0; s < HC; ++s) zz += zreg[s] * zreg[s];
-  zz += __shfl_xor(zz, 32, 64);
   if (split == 0 && rvalid) {
     float* op = zn_out + row * C + HC * hf;
 #pragma unroll
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
       const int r = f / (C / 4), c4 = f % (C / 4);
       est[ps] = (c0 + r < lim) ? ld4(en + (int64_t)(c0 + r) * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    if (tid < CODES_LDS) eest = (c0 + tid < lim) ? ee[c0 + tid] : INFINITY;  // +inf distance: never chosen
+    if (tid < CODES_LDS) eest = (c0 + tid < lim) ? ee[c0 + tid] : INFINITY;
   };
   auto commit = [&]() {
 #pragma unroll
@@ -132,10 +133,13 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
       const int r = f / (C / 4), c4 = f % (C / 4);
       st4(&Es[r * LS + 4 * c4], est[ps]);
     }
-    if (tid < CODES_LDS) EEs[tid] = eest;
+    if (tid < CODES_LDS) EEs[tid] = -0.5f * eest;   // padding: ee = +inf -> score -inf, never chosen
   };
 
-  float best = INFINITY;
+  // vq.hip is compiled with -fno-honor-nans -mno-amdgpu-ieee (Makefile): fmaxf is then a bare
+  // v_max_f32 / v_max3_f32 with no canonicalising v_max(x, x) in front of it
+  auto vmax = [&](float a, float b) { return fmaxf(a, b); };
+  float best = -INFINITY;
   int bbase = kbeg, bsub = 0;
   prefetch(0);
   for (int t = 0; t < ntile; ++t) {
@@ -145,43 +149,68 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
     if (t + 1 < ntile) prefetch(t + 1);
     const int c0 = kbeg + t * CODES_LDS;
     const int nsub = min(CODES_LDS, kper - t * CODES_LDS) / 32;
-    for (int u = 0; u < nsub; ++u) {
-      f32x16 acc;
+    // -ee/2 of this half-wave's 16 codes of sub-tile u, in accumulator order: the loads go
+    // straight into the registers the MFMA chain uses as its C operand
+    auto load_init = [&](int u) {
+      f32x16 a;
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+      for (int g = 0; g < 4; ++g) {
+        const float4 n = ld4(&EEs[32 * u + 8 * g + 4 * hf]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a[4 * g + e] = f4(n, e);
+      }
+      return a;
+    };
+    struct AHead { float4 a0, a1; };  // first half of the A operand (codes) of a sub-tile
+    auto load_head = [&](int u) {
+      const float* er = &Es[(32 * u + ln) * LS + HC * hf];
+      return AHead{ld4(er), ld4(er + 4)};
+    };
+    auto subtile = [&](int u, f32x16 acc, const AHead& hd) {
       const float* er = &Es[(32 * u + ln) * LS + HC * hf];
 #pragma unroll
       for (int s4 = 0; s4 < HC / 4; ++s4) {
-        const float4 a = ld4(er + 4 * s4);
+        const float4 a = s4 == 0 ? hd.a0 : (s4 == 1 ? hd.a1 : ld4(er + 4 * s4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(f4(a, e), zreg[4 * s4 + e], acc);
       }
-      // Running (min, argmin).  Every VALU instruction is paid against the f32 MFMA pipe, so the
-      // index is kept as (sub-tile base, register number): the per-element select then takes the
-      // register number as an inline constant, and the base moves once per sub-tile.
-      const float before = best;
+      // acc[r] = dot - ee/2 for code (r&3) + 8*(r>>2) + 4*half of the sub-tile: registers 4g..4g+3
+      // are 4 consecutive codes.  Running max over groups; the index is (sub-tile base, group).
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 e4 = ld4(&EEs[32 * u + 8 * g + 4 * hf]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          // (sum z^2 + sum e^2) - 2*dot : same association as the reference expression
-          const float d = __builtin_fmaf(-2.f, acc[r], zz + f4(e4, e));
-          const bool lt = d < best;  // strict: the first minimum wins, codes ascend per lane
-          best = lt ? d : best;
-          bsub = lt ? r : bsub;
-        }
+        const float gm = vmax(vmax(acc[4 * g], acc[4 * g + 1]), vmax(acc[4 * g + 2], acc[4 * g + 3]));
+        const bool gt = gm > best;   // strict: the first maximum wins, groups ascend per lane
+        best = vmax(best, gm);
+        bsub = gt ? 4 * u + g : bsub;  // an inline constant in the unrolled tile
       }
-      bbase = (best != before) ? (c0 + 32 * u) : bbase;
+    };
+    const float before = best;
+    if (nsub == CODES_LDS / 32) {
+      // full tile, unrolled with two accumulator sets: the C-operand loads of sub-tile u+1 are
+      // issued before the MFMAs of sub-tile u, so their LDS latency is never exposed
+      f32x16 cur = load_init(0);
+      AHead hcur = load_head(0);
+#pragma unroll
+      for (int u = 0; u < CODES_LDS / 32; ++u) {
+        f32x16 nxt = cur;
+        AHead hnxt = hcur;
+        if (u + 1 < CODES_LDS / 32) { nxt = load_init(u + 1); hnxt = load_head(u + 1); }
+        __builtin_amdgcn_sched_barrier(0);
+        subtile(u, cur, hcur);
+        cur = nxt;
+        hcur = hnxt;
+      }
+    } else {
+      for (int u = 0; u < nsub; ++u) subtile(u, load_init(u), load_head(u));
     }
+    bbase = (best != before) ? c0 : bbase;  // the tile base moves once per LDS tile
   }
-  // code = sub-tile base + row of accumulator register bsub for this half-wave
-  int bidx = bbase + (bsub & 3) + 8 * (bsub >> 2) + 4 * hf;
-  // merge the two half-waves of a row (they own interleaved codes): lowest index on ties
+  // first code of the winning group: tile base + 32 * sub-tile + 8 * group + 4 * half
+  int bidx = bbase + 8 * bsub + 4 * hf;
+  // merge the two half-waves of a row (they own interleaved groups): lowest group on ties
   const float ob = __shfl_xor(best, 32, 64);
   const int oi = __shfl_xor(bidx, 32, 64);
-  if (ob < best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
+  if (ob > best || (ob == best && oi < bidx)) { best = ob; bidx = oi; }
   if (rvalid && hf == 0) {
     pmin[row * nsplit + split] = best;
     pidx[row * nsplit + split] = bidx;
@@ -191,7 +220,8 @@ __global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(FIN_ROWS * C / 4) void vq_finalize_kernel(
-    const float* __restrict__ E, const float* __restrict__ zn, const float* __restrict__ pmin,
+    const float* __restrict__ E, const float* __restrict__ en, const float* __restrict__ ee,
+    const float* __restrict__ zn, const float* __restrict__ pmin,
     const int32_t* __restrict__ pidx, int64_t N, int nsplit, int64_t* __restrict__ idx,
     float* __restrict__ out, float* __restrict__ zq_out, float* __restrict__ sqerr_partial) {
   constexpr int LPR = C / 4;
@@ -202,10 +232,24 @@ __global__ __launch_bounds__(FIN_ROWS * C / 4) void vq_finalize_kernel(
   float err = 0.f;
   if (row < N) {
     float best = pmin[row * nsplit];
-    int bi = pidx[row * nsplit];
-    for (int s = 1; s < nsplit; ++s) {  // slices hold ascending code ranges: strict '<' keeps the first minimum
+    int bg = pidx[row * nsplit];
+    for (int s = 1; s < nsplit; ++s) {  // slices hold ascending code ranges: strict '>' keeps the first maximum
       const float d = pmin[row * nsplit + s];
-      if (d < best) { best = d; bi = pidx[row * nsplit + s]; }
+      if (d > best) { best = d; bg = pidx[row * nsplit + s]; }
+    }
+    // rank the 4 consecutive codes of the winning group: score = <zn, en[k]> - ee[k]/2, the lanes
+    // of the row each take 4 channels; every lane uses the first lane's sums so the row agrees.
+    const float4 zv = ld4(zn + row * C + c);
+    int bi = bg;
+    float bs = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 ev = ld4(en + (int64_t)(bg + j) * C + c);
+      float sc = zv.x * ev.x + zv.y * ev.y + zv.z * ev.z + zv.w * ev.w;
+#pragma unroll
+      for (int o = LPR / 2; o >= 1; o >>= 1) sc += __shfl_xor(sc, o, 64);
+      sc = __shfl(sc, (threadIdx.x & 63) & ~(LPR - 1), 64) - 0.5f * ee[bg + j];
+      if (sc > bs) { bs = sc; bi = bg + j; }
     }
     const float4 e = ld4(E + (int64_t)bi * C + c);
     float ss = e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
@@ -213,7 +257,6 @@ __global__ __launch_bounds__(FIN_ROWS * C / 4) void vq_finalize_kernel(
     for (int o = LPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float denom = fmaxf(sqrtf(ss), EPS);
     const float4 q = make_float4(e.x / denom, e.y / denom, e.z / denom, e.w / denom);
-    const float4 zv = ld4(zn + row * C + c);
     const float4 df = make_float4(q.x - zv.x, q.y - zv.y, q.z - zv.z, q.w - zv.w);
     st4(zq_out + row * C + c, q);
     st4(out + row * C + c, make_float4(zv.x + df.x, zv.y + df.y, zv.z + df.z, zv.w + df.w));
@@ -301,7 +344,7 @@ int launch_fwd(const float* z, const float* E, int64_t N, int K, int nsplit, flo
   hipLaunchKernelGGL(vq_argmin_kernel<C>, dim3((unsigned)(nrb * nsplit)), dim3(256), 0, st, z, en, ee, N, K, nsplit, zn,
                      pmin, pidx);
   hipLaunchKernelGGL(vq_finalize_kernel<C>, dim3((unsigned)((N + FIN_ROWS - 1) / FIN_ROWS)), dim3(FIN_ROWS * LPR), 0, st,
-                     E, zn, pmin, pidx, N, nsplit, idx, out, zq, sqerr);
+                     E, en, ee, zn, pmin, pidx, N, nsplit, idx, out, zq, sqerr);
   return 0;
 }
 
