@@ -35,6 +35,10 @@ SIGNATURES = {
     "amk_agent_ws_floats": (_L, [_I, _I, _I, _I, _I]),
     "amk_agent_attn_fwd": (_I, [_P] * 10 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_agent_attn_bwd": (_I, [_P] * 14 + [_I] * 5 + [_L] * 21 + [_F, _P]),
+    "amk_rowsum_num_partials": (_I, [_L]),
+    "amk_add_layernorm_fwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
+    "amk_add_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "amk_colsum": (_I, [_P, _L, _I, _P, _P]),
     "amk_swiglu_fwd": (_I, [_P, _L, _I, _P, _P]),
     "amk_swiglu_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
     "amk_moe_route_ws_ints": (_L, [_L, _I, _I]),

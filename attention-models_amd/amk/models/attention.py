@@ -8,6 +8,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from .layers import Linear
 from .moe import StackedExpertsMixin, linear_like_init_
 
 
@@ -29,7 +30,7 @@ class SoftmaxAttention(nn.Module):
         # Sequential containers only to keep the reference's "q.0.weight"/"kv.0.weight" keys.
         self.q = nn.Sequential(nn.Linear(dim, inner, bias=False))
         self.kv = nn.Sequential(nn.Linear(dim, 2 * inner, bias=False))
-        self.W_o = nn.Linear(inner, dim)
+        self.W_o = Linear(inner, dim)
         self.dropout_p = float(dropout)
         self.scale = dim_head ** -0.5
 
@@ -134,7 +135,7 @@ class AgentAttention(nn.Module):
         inner = num_heads * dim_head
         self.qkv = nn.Linear(dim, 3 * inner, bias=False)
         self.scale = dim_head ** -0.5
-        self.W_o = nn.Linear(inner, dim)
+        self.W_o = Linear(inner, dim)
         self.dropout_p = float(dropout)
         self.bias1 = nn.Parameter(torch.zeros(1, 1, 1, 1))
         self.bias2 = nn.Parameter(torch.zeros(1, 1, 1, 1))

@@ -1,0 +1,29 @@
+"""nn.Linear / nn.LayerNorm with the same parameters and state_dict keys, routed through the
+epilogue kernels of libamk.so (amk_add_layernorm_*, amk_colsum) when the input is on the GPU."""
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .. import ops
+
+
+class Linear(nn.Linear):
+    def forward(self, x):
+        if self.bias is None or not x.is_cuda:
+            return F.linear(x, self.weight, self.bias)
+        return ops.linear(x, self.weight, self.bias)
+
+
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm over the last axis.  ``forward(x)`` = LN(x); ``forward(x, residual)`` returns
+    ``(x + residual, LN(x + residual))`` from one kernel."""
+
+    def forward(self, x, residual=None):
+        fusable = x.is_cuda and self.elementwise_affine and self.bias is not None and len(self.normalized_shape) == 1
+        if residual is None:
+            if not fusable:
+                return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
+            return ops.layer_norm(x, self.weight, self.bias, self.eps)
+        if not fusable:
+            h = x + residual
+            return h, F.layer_norm(h, self.normalized_shape, self.weight, self.bias, self.eps)
+        return ops.add_layer_norm(x, residual, self.weight, self.bias, self.eps)

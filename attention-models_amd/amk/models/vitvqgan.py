@@ -18,6 +18,7 @@ import torch.nn.functional as F
 
 from .. import ops
 from .attention import SoftmaxAttention
+from .layers import LayerNorm, Linear
 
 
 def l2_norm(x):
@@ -27,8 +28,8 @@ def l2_norm(x):
 class SwiGLU(nn.Module):
     def __init__(self, in_features, hidden_features, out_features, bias=True):
         super().__init__()
-        self.w12 = nn.Linear(in_features, 2 * hidden_features, bias=bias)
-        self.w3 = nn.Linear(hidden_features, out_features, bias=bias)
+        self.w12 = Linear(in_features, 2 * hidden_features, bias=bias)
+        self.w3 = Linear(hidden_features, out_features, bias=bias)
 
     def forward(self, x):
         ab = self.w12(x)  # (..., 2*hidden) = (a | b)
@@ -51,12 +52,23 @@ class EncoderLayer(nn.Module):
         super().__init__()
         self.self_attn = SoftmaxAttention(dim, n_heads, d_head, dropout)
         self.feed_forward = FeedForward(dim, mlp_dim)
-        self.norm1 = nn.LayerNorm(dim)
-        self.norm2 = nn.LayerNorm(dim)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
 
     def forward(self, x):
         x = x + self.self_attn(self.norm1(x))
         return x + self.feed_forward(self.norm2(x))
+
+    def forward_fused(self, h, pending):
+        """The same block on a residual stream kept as (h, pending): the stream's value is h + pending
+        and each add is done inside the LayerNorm kernel that consumes it (amk_add_layernorm_fwd).
+        Returns the new (h, pending)."""
+        if pending is None:
+            y = self.norm1(h)
+        else:
+            h, y = self.norm1(h, pending)
+        h, y = self.norm2(h, self.self_attn(y))
+        return h, self.feed_forward(y)
 
 
 class TransformerBlock(nn.Module):
@@ -65,9 +77,10 @@ class TransformerBlock(nn.Module):
         self.layers = nn.ModuleList(EncoderLayer(dim, n_heads, d_head, mlp_dim, dropout) for _ in range(depth))
 
     def forward(self, x):
+        h, pending = x, None
         for blk in self.layers:
-            x = blk(x)
-        return x
+            h, pending = blk.forward_fused(h, pending)
+        return h if pending is None else h + pending
 
 
 class Patchify(nn.Module):
@@ -100,10 +113,10 @@ class ViTEncoder(nn.Module):
         patch_dim = 3 * patch_size * patch_size
         n_patches = (img_size // patch_size) ** 2
         self.to_patch_embedding = nn.Sequential(
-            Patchify(patch_size), nn.LayerNorm(patch_dim), nn.Linear(patch_dim, dim), nn.LayerNorm(dim)
+            Patchify(patch_size), LayerNorm(patch_dim), Linear(patch_dim, dim), LayerNorm(dim)
         )
         self.pos_enc = nn.Parameter(torch.randn(1, n_patches, dim))
-        self.pre_norm = nn.LayerNorm(dim)
+        self.pre_norm = LayerNorm(dim)
         self.encoder = TransformerBlock(dim, n_heads, d_head, depth, mlp_dim, dropout)
 
     def forward(self, img):
@@ -119,9 +132,9 @@ class ViTDecoder(nn.Module):
         patch_dim = 3 * patch_size * patch_size
         n_patches = (img_size // patch_size) ** 2
         self.pos_enc = nn.Parameter(torch.randn(1, n_patches, dim))
-        self.pre_norm = nn.LayerNorm(dim)
+        self.pre_norm = LayerNorm(dim)
         self.decoder = TransformerBlock(dim, n_heads, d_head, depth, mlp_dim, dropout)
-        self.fc = nn.Linear(dim, patch_dim)
+        self.fc = Linear(dim, patch_dim)
 
     def forward(self, tok):
         tok = self.decoder(self.pre_norm(tok + self.pos_enc))
@@ -154,9 +167,9 @@ class ViTVQGAN(nn.Module):
     def __init__(self, vit_params, codebook_params):
         super().__init__()
         self.encoder = ViTEncoder(**vit_params)
-        self.pre_quant = nn.Linear(vit_params["dim"], codebook_params["codebook_dim"])
+        self.pre_quant = Linear(vit_params["dim"], codebook_params["codebook_dim"])
         self.codebook = Codebook(**codebook_params)
-        self.post_quant = nn.Linear(codebook_params["codebook_dim"], vit_params["dim"])
+        self.post_quant = Linear(codebook_params["codebook_dim"], vit_params["dim"])
         self.decoder = ViTDecoder(**vit_params)
 
     def forward(self, imgs):

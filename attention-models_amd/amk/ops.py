@@ -513,3 +513,131 @@ class _SwiGLU(torch.autograd.Function):
 def swiglu(ab):
     """silu(a) * b for ab = (..., 2H) = (a | b): one HBM pass forward, one backward."""
     return _SwiGLU.apply(ab)
+
+
+# ---------------------------------------------------------------------------- residual + LayerNorm
+def _ln_supported(D):
+    return D % 4 == 0 and D <= 4096
+
+
+def _ln_backward(dy, h, dh_in, weight, mean, rstd):
+    M, D = h.shape
+    L = _lib.load()
+    dh = torch.empty_like(h)
+    part = torch.empty((L.amk_rowsum_num_partials(M), 2, D), device=h.device, dtype=torch.float32)
+    _lib.check(L.amk_add_layernorm_bwd(_ptr(dy), _ptr(h), _ptr(dh_in), _ptr(weight), _ptr(mean), _ptr(rstd),
+                                       M, D, _ptr(dh), _ptr(part), _stream()), "amk_add_layernorm_bwd")
+    dgb = part.sum(0)
+    return dh, dgb[0], dgb[1]
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        _require_device(x, weight, bias)
+        D = x.shape[-1]
+        x2 = x.contiguous().view(-1, D)
+        M = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        w, b = weight.contiguous(), bias.contiguous()
+        L = _lib.load()
+        _lib.check(L.amk_add_layernorm_fwd(_ptr(x2), _NULL, _ptr(w), _ptr(b), M, D, float(eps), _NULL, _ptr(y),
+                                           _ptr(mean), _ptr(rstd), _stream()), "amk_add_layernorm_fwd")
+        ctx.save_for_backward(x2, w, mean, rstd)
+        ctx.shape = x.shape
+        return y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, mean, rstd = ctx.saved_tensors
+        dx, dw, db = _ln_backward(dy.contiguous().view(x2.shape), x2, None, w, mean, rstd)
+        return dx.view(ctx.shape), dw, db, None
+
+
+class _AddLayerNorm(torch.autograd.Function):
+    """(x, res) -> (h, y) with h = x + res, y = LN(h); the gradient of h is added inside the LN backward."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        _require_device(x, res, weight, bias)
+        D = x.shape[-1]
+        x2 = x.contiguous().view(-1, D)
+        r2 = res.contiguous().view(-1, D)
+        M = x2.shape[0]
+        h = torch.empty_like(x2)
+        y = torch.empty_like(x2)
+        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        w, b = weight.contiguous(), bias.contiguous()
+        L = _lib.load()
+        _lib.check(L.amk_add_layernorm_fwd(_ptr(x2), _ptr(r2), _ptr(w), _ptr(b), M, D, float(eps), _ptr(h), _ptr(y),
+                                           _ptr(mean), _ptr(rstd), _stream()), "amk_add_layernorm_fwd")
+        ctx.save_for_backward(h, w, mean, rstd)
+        ctx.shape = x.shape
+        ctx.set_materialize_grads(False)
+        return h.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dh_in, dy):
+        h, w, mean, rstd = ctx.saved_tensors
+        if dy is None:  # y unused downstream: only the residual stream carries gradient
+            if dh_in is None:
+                return None, None, None, None, None
+            return dh_in, dh_in, None, None, None
+        dh2 = dh_in.contiguous().view(h.shape) if dh_in is not None else None
+        dh, dw, db = _ln_backward(dy.contiguous().view(h.shape), h, dh2, w, mean, rstd)
+        dh = dh.view(ctx.shape)
+        return dh, dh, dw, db, None
+
+
+def layer_norm(x, weight, bias, eps=1e-5):
+    """LayerNorm over the last axis (one HBM pass forward, one backward incl. the gamma / beta partials)."""
+    if not _ln_supported(x.shape[-1]):
+        return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+    return _LayerNorm.apply(x, weight, bias, eps)
+
+
+def add_layer_norm(x, res, weight, bias, eps=1e-5):
+    """h = x + res, y = LayerNorm(h): returns (h, y) from one kernel (amk_add_layernorm_fwd)."""
+    if not _ln_supported(x.shape[-1]):
+        h = x + res
+        return h, torch.nn.functional.layer_norm(h, (h.shape[-1],), weight, bias, eps)
+    return _AddLayerNorm.apply(x, res, weight, bias, eps)
+
+
+# ---------------------------------------------------------------------------- Linear with bias
+def colsum(x2):
+    """Column sums of a contiguous (M, N) matrix (the bias gradient of a Linear)."""
+    M, N = x2.shape
+    if N % 4 != 0 or N > 1024:  # wide matrices: torch's reduction is as fast (measured at N = 2736: 71 vs 88 us)
+        return x2.sum(0)
+    L = _lib.load()
+    part = torch.empty((L.amk_rowsum_num_partials(M), N), device=x2.device, dtype=torch.float32)
+    _lib.check(L.amk_colsum(_ptr(x2), M, N, _ptr(part), _stream()), "amk_colsum")
+    return part.sum(0)
+
+
+class _BiasLinear(torch.autograd.Function):
+    """F.linear with bias; the GEMMs stay with the vendor library (same calls autograd would make, so
+    the shipped TunableOp selections apply), the bias gradient is amk_colsum instead of a strided sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_device(x, weight, bias)
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, dy.shape[-1])
+        dx = dy2.mm(weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        dw = dy2.t().mm(x.reshape(-1, x.shape[-1])) if ctx.needs_input_grad[1] else None
+        db = colsum(dy2) if ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def linear(x, weight, bias):
+    return _BiasLinear.apply(x, weight, bias)

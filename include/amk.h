@@ -234,6 +234,26 @@ int amk_agent_attn_bwd(const float* q, const float* k, const float* v, const flo
                        int64_t dv_sb, int64_t dv_st, int64_t dv_sh, float scale, void* stream);
 
 /* --------------------------------------------------------------------------
+ * Residual-add + LayerNorm and the bias-gradient column sum (the
+ * pre-LN / residual epilogues around the attention and FFN of models/vitvqgan.py:44-61 and
+ * models/transformer.py:11-19,58-76).
+ *   forward : h = x + res (written only when res != NULL; then h != NULL too);  y = LN(h)*gamma + beta
+ *             mean, rstd (M) are saved for the backward.  eps as torch.nn.LayerNorm (1e-5 default).
+ *   backward: dh = LN'(dy) + dh_in (dh_in may be NULL); dgb_part (amk_rowsum_num_partials(M), 2, D)
+ *             holds per-workgroup partial sums of dgamma (row 0) and dbeta (row 1): the caller sums axis 0.
+ *             `h` is the forward's h (or x when there was no residual).
+ *   colsum  : part (amk_rowsum_num_partials(M), N) partial column sums of x (M, N); caller sums axis 0.
+ * Widths: multiples of 4 up to 4096; all matrices row-major contiguous; HBM-bound, one pass each.
+ * -------------------------------------------------------------------------- */
+int amk_rowsum_num_partials(int64_t M);
+int amk_add_layernorm_fwd(const float* x, const float* res, const float* gamma, const float* beta,
+                          int64_t M, int D, float eps, float* h, float* y, float* mean, float* rstd, void* stream);
+int amk_add_layernorm_bwd(const float* dy, const float* h, const float* dh_in, const float* gamma,
+                          const float* mean, const float* rstd, int64_t M, int D, float* dh, float* dgb_part,
+                          void* stream);
+int amk_colsum(const float* x, int64_t M, int N, float* part, void* stream);
+
+/* --------------------------------------------------------------------------
  * Fused SwiGLU gate (epilogue of the ViT-VQGAN FFN):
  *   out[m, j] = silu(ab[m, j]) * ab[m, H + j]      ab: (M, 2H) = w12(x), out: (M, H)
  * replaces chunk -> silu -> mul of the SwiGLU the reference's FeedForward keywords describe
