@@ -6,6 +6,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .attention import SoftmaxAttention
 
 
@@ -19,6 +20,8 @@ class LayerNorm(nn.Module):
         self.register_buffer("beta", torch.zeros(dim))
 
     def forward(self, x):
+        if x.is_cuda:
+            return ops.layer_norm(x, self.gamma, self.beta)   # amk_add_layernorm_fwd / _bwd
         return F.layer_norm(x, x.shape[-1:], self.gamma, self.beta)
 
 

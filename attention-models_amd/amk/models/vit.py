@@ -9,6 +9,7 @@ parameter counts (33,629,160 at the config-2 size) match.
 import torch
 import torch.nn as nn
 
+from .layers import LayerNorm
 from .transformer import Encoder
 from .vitvqgan import Patchify
 
@@ -30,8 +31,8 @@ class ViT(nn.Module):
         self.dim = dim
         self.patch_size = patch_size
         self.patch_dim = 3 * patch_size * patch_size
-        self.to_patch_embedding = nn.Sequential(Patchify(patch_size), nn.LayerNorm(self.patch_dim),
-                                                nn.Linear(self.patch_dim, dim), nn.LayerNorm(dim))
+        self.to_patch_embedding = nn.Sequential(Patchify(patch_size), LayerNorm(self.patch_dim),
+                                                nn.Linear(self.patch_dim, dim), LayerNorm(dim))
         self.final_fc = nn.Linear(dim, num_classes)
         self.class_token = nn.Parameter(torch.randn(dim))
         n_patches = (image_size // patch_size) ** 2

@@ -4,6 +4,7 @@ SwitchHead experts and the MoE FFN, as in the reference (models/vit_moe.py:26-27
 import torch
 import torch.nn as nn
 
+from .layers import LayerNorm
 from .attention import SwitchHeadAttention
 from .moe import MoELayer
 from .vitvqgan import Patchify
@@ -15,8 +16,8 @@ class EncoderLayer(nn.Module):
         self.self_attn = SwitchHeadAttention(dim, n_heads, d_head, num_experts=n_experts, sel_experts=sel_experts,
                                              dropout=dropout)
         self.moe = MoELayer(input_dim=dim, output_dim=dim, num_experts=n_experts, sel_experts=sel_experts)
-        self.norm1 = nn.LayerNorm(dim)
-        self.norm2 = nn.LayerNorm(dim)
+        self.norm1 = LayerNorm(dim)
+        self.norm2 = LayerNorm(dim)
 
     def forward(self, x, context_mask=None):
         x = self.self_attn(x=self.norm1(x), context_mask=context_mask) + x
@@ -42,13 +43,13 @@ class ViTMoE(nn.Module):
         self.dim = dim
         self.patch_size = patch_size
         self.patch_dim = 3 * patch_size * patch_size
-        self.to_patch_embedding = nn.Sequential(Patchify(patch_size), nn.LayerNorm(self.patch_dim),
-                                                nn.Linear(self.patch_dim, dim), nn.LayerNorm(dim))
+        self.to_patch_embedding = nn.Sequential(Patchify(patch_size), LayerNorm(self.patch_dim),
+                                                nn.Linear(self.patch_dim, dim), LayerNorm(dim))
         self.class_token = nn.Parameter(torch.randn(1, 1, dim))
         n_patches = (image_size // patch_size) ** 2
         self.pos_enc = nn.Parameter(torch.randn(1, n_patches + 1, dim))
         self.encoder = Encoder(dim, n_heads, d_head, depth, n_experts, sel_experts, dropout)
-        self.norm = nn.LayerNorm(dim)
+        self.norm = LayerNorm(dim)
         self.class_embed = nn.Linear(dim, num_classes)
 
     def forward(self, x):

@@ -517,7 +517,7 @@ def swiglu(ab):
 
 # ---------------------------------------------------------------------------- residual + LayerNorm
 def _ln_supported(D):
-    return D % 4 == 0 and D <= 4096
+    return 0 < D <= 4096 and D % 4 == 0
 
 
 def _ln_backward(dy, h, dh_in, weight, mean, rstd):
@@ -594,14 +594,14 @@ class _AddLayerNorm(torch.autograd.Function):
 
 def layer_norm(x, weight, bias, eps=1e-5):
     """LayerNorm over the last axis (one HBM pass forward, one backward incl. the gamma / beta partials)."""
-    if not _ln_supported(x.shape[-1]):
+    if not _ln_supported(x.shape[-1]) or x.numel() == 0:
         return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
 def add_layer_norm(x, res, weight, bias, eps=1e-5):
     """h = x + res, y = LayerNorm(h): returns (h, y) from one kernel (amk_add_layernorm_fwd)."""
-    if not _ln_supported(x.shape[-1]):
+    if not _ln_supported(x.shape[-1]) or x.numel() == 0:
         h = x + res
         return h, torch.nn.functional.layer_norm(h, (h.shape[-1],), weight, bias, eps)
     return _AddLayerNorm.apply(x, res, weight, bias, eps)
