@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 
 from .dp import GradReducer
+from .models.discriminator import input_grad_only
 
 
 def set_requires_grad(module, flag):
@@ -60,8 +61,9 @@ class VQGANTrainStep:
         eta = torch.rand(real.shape[0], 1, 1, 1, device=real.device)
         mixed = (eta * real + (1.0 - eta) * fake).detach().requires_grad_(True)
         pred = self.discr(mixed)
-        (grad,) = torch.autograd.grad(pred, mixed, grad_outputs=torch.ones_like(pred),
-                                      create_graph=True, retain_graph=True)
+        with input_grad_only():   # only d pred / d mixed is asked for: skip the weight gradients
+            (grad,) = torch.autograd.grad(pred, mixed, grad_outputs=torch.ones_like(pred),
+                                          create_graph=True, retain_graph=True)
         return ((grad.norm(2, dim=1) - 1.0) ** 2).mean() * self.gp_lambda
 
     def _set_lr(self):

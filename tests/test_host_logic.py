@@ -100,3 +100,46 @@ def test_grad_reducer_bucket_layout():
     red.zero_grad()
     assert all(float(b.flat.abs().sum()) == 0.0 for b in red.buckets)
     assert red.grads_nbytes() == sum(p.numel() for p in params) * 4
+
+
+def test_discriminator_conv_second_order_matches_nn_conv2d():
+    """amk.models.discriminator.Conv2d restates the convolution's first and second derivatives with
+    ordinary forward / data-gradient / weight-gradient calls; the gradient-penalty step must give the
+    same parameter gradients as plain nn.Conv2d (trainers/vitgqgan.py:115-131 structure)."""
+    import torch.nn as nn
+
+    from amk.models.discriminator import NLayerDiscriminator, input_grad_only
+
+    torch.manual_seed(0)
+    ours = NLayerDiscriminator(3, 8, 3).double()
+    ref = nn.Sequential()
+    for i, m in enumerate(ours.model):
+        if isinstance(m, nn.Conv2d):
+            c = nn.Conv2d(m.in_channels, m.out_channels, 4, stride=m.stride, padding=1, bias=m.bias is not None).double()
+            c.load_state_dict(m.state_dict())
+            ref.append(c)
+        elif isinstance(m, nn.BatchNorm2d):
+            ref.append(nn.BatchNorm2d(m.num_features).double())
+        else:
+            ref.append(nn.LeakyReLU(0.2, True))
+    real = torch.rand(3, 3, 64, 64, dtype=torch.double)
+    fake = torch.rand(3, 3, 64, 64, dtype=torch.double)
+    eta = torch.rand(3, 1, 1, 1, dtype=torch.double)
+
+    def d_loss(net, guard):
+        mixed = (eta * real + (1 - eta) * fake).requires_grad_(True)
+        pred = net(mixed)
+        with guard():
+            (g,) = torch.autograd.grad(pred, mixed, grad_outputs=torch.ones_like(pred), create_graph=True, retain_graph=True)
+        gp = ((g.norm(2, dim=1) - 1.0) ** 2).mean() * 10.0
+        return torch.relu(1.0 - net(real)).mean() + torch.relu(1.0 + net(fake)).mean() + gp
+
+    import contextlib
+    la = d_loss(ours, input_grad_only)
+    lb = d_loss(ref, contextlib.nullcontext)
+    assert abs(float(la) - float(lb)) < 1e-10 * max(1.0, abs(float(lb)))
+    ga = torch.autograd.grad(la, list(ours.parameters()))
+    gb = torch.autograd.grad(lb, list(ref.parameters()))
+    assert len(ga) == len(gb)
+    for a, b in zip(ga, gb):
+        assert float((a - b).abs().max()) <= 1e-9 * max(1.0, float(b.abs().max()))
