@@ -42,7 +42,8 @@ def cosine_warmup_lr(step, base_lr, t_initial, warmup_t, warmup_lr_init=1e-6, lr
 class VQGANTrainStep:
     def __init__(self, model, discr, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0,
                  adv_loss_weight=0.1, logit_laplace_weight=1.0, max_grad_norm=1.0,
-                 warmup_steps=50000, decay_steps=100000, gp_lambda=10.0, bucket_bytes=32 << 20):
+                 warmup_steps=50000, decay_steps=100000, gp_lambda=10.0, bucket_bytes=32 << 20,
+                 share_forward=False):
         self.model, self.discr = model, discr
         self.adv_w, self.laplace_w = adv_loss_weight, logit_laplace_weight
         self.max_grad_norm, self.gp_lambda = max_grad_norm, gp_lambda
@@ -55,6 +56,13 @@ class VQGANTrainStep:
         self.g_red.broadcast_parameters()
         self.d_red.broadcast_parameters()
         self.global_step = 0
+        # The reference runs the generator forward twice per step on the same images with unchanged
+        # generator weights (trainers/vitgqgan.py:149 and :169; only the discriminator steps in
+        # between).  share_forward=True runs it once, with the autograd graph, and hands the
+        # discriminator phase a detached reconstruction: the same numbers while dropout is 0 (every
+        # shipped config), one generator forward less.  Off by default: the step then mirrors the
+        # reference call for call.
+        self.share_forward = bool(share_forward)
 
     def gradient_penalty(self, real, fake):
         """trainers/vitgqgan.py:115-131."""
@@ -76,10 +84,17 @@ class VQGANTrainStep:
         model, discr = self.model, self.discr
         self._set_lr()
         # ---- discriminator phase (reference :146-163)
-        set_requires_grad(model, False)
+        shared = None
+        if self.share_forward:
+            set_requires_grad(model, True)
+            shared = model(img)
+            rec = shared[0].detach()
+        else:
+            set_requires_grad(model, False)
         set_requires_grad(discr, True)
         self.d_red.begin(sync)
-        rec, _ = model(img)
+        if shared is None:
+            rec, _ = model(img)
         d_loss = hinge_d_loss(discr(rec), discr(img)) + self.gradient_penalty(img, rec)
         d_loss.backward()
         self.d_red.finish()
@@ -92,7 +107,7 @@ class VQGANTrainStep:
         set_requires_grad(model, True)
         set_requires_grad(discr, False)
         self.g_red.begin(sync)
-        rec, codebook_loss = model(img)
+        rec, codebook_loss = shared if shared is not None else model(img)
         l1 = F.l1_loss(rec, img)
         l2 = F.mse_loss(rec, img)
         g_loss = g_nonsaturating_loss(discr(rec))

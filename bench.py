@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--kernel-iters", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the informational shared-forward variant")
     return ap.parse_args()
 
 
@@ -182,6 +183,25 @@ def main():
     loss = float(logs["loss"])
     note(f"timed {args.steps} steps in {dt:.3f}s")
 
+    # informational variant (never `value`): the same step with the generator forward shared by the
+    # two phases (VQGANTrainStep(share_forward=True); identical numbers while dropout is 0)
+    shared = None
+    if world == 1 and not args.no_variants:
+        trainer.share_forward = True
+        for _ in range(2):
+            trainer.step(imgs)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(imgs)
+        sync()
+        ds = time.perf_counter() - t1
+        trainer.share_forward = False
+        shared = {"value": args.batch * args.steps / ds, "unit": "images/s", "ms_per_step": ds / args.steps * 1e3,
+                  "what": "generator forward run once per step and shared by the discriminator and generator "
+                          "phases (the reference runs it twice on unchanged weights); not the headline value"}
+        note("shared-forward variant done")
+
     kernels = None
     if rank == 0 and not args.no_kernels:
         kernels = kernel_rooflines(args.batch, dev, args.kernel_iters)
@@ -259,6 +279,8 @@ def main():
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac_of_f32_mfma_peak"],
                 "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "flop_per_launch": dom["flop"],
             }
+        if shared:
+            line["variant_shared_generator_forward"] = shared
         if kernels:
             line["kernels_microbench"] = kernels
         if cpu:

@@ -203,3 +203,33 @@ def test_hip_graph_capture_of_a_train_step(device):
     for (n, a), (_, b) in zip(eager.named_parameters(), graphed.named_parameters()):
         if a.grad is not None:
             assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max())), n
+
+
+def test_train_step_shared_forward_is_the_same_step(device):
+    """VQGANTrainStep(share_forward=True) = the reference-shaped step with the duplicated generator
+    forward removed: same losses and same parameters after two steps (dropout 0)."""
+    import copy
+
+    from amk.models import ViTVQGAN
+    from amk.models.discriminator import NLayerDiscriminator
+    from amk.train import VQGANTrainStep
+
+    vit = dict(dim=64, img_size=32, patch_size=8, n_heads=1, d_head=64, depth=1, mlp_dim=128, dropout=0.0)
+    torch.manual_seed(0)
+    model = ViTVQGAN(vit, dict(codebook_size=64, codebook_dim=32)).to(device)
+    discr = NLayerDiscriminator(3, 8, 3).to(device)
+    model2, discr2 = copy.deepcopy(model), copy.deepcopy(discr)
+    imgs = torch.rand(4, 3, 32, 32, device=device)
+    a = VQGANTrainStep(model, discr, warmup_steps=1, share_forward=False)
+    b = VQGANTrainStep(model2, discr2, warmup_steps=1, share_forward=True)
+    for _ in range(2):
+        torch.manual_seed(5)   # the gradient penalty draws eta
+        la = a.step(imgs)
+        torch.manual_seed(5)
+        lb = b.step(imgs)
+        for k in la:
+            assert float((la[k] - lb[k]).abs()) <= 1e-5 * max(1.0, float(la[k].abs())), k
+    for (n, p), q in zip(model.named_parameters(), model2.parameters()):
+        assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), n
+    for (n, p), q in zip(discr.named_parameters(), discr2.parameters()):
+        assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), n
