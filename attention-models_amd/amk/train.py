@@ -122,3 +122,19 @@ class VQGANTrainStep:
         self.global_step += 1
         return dict(d_loss=d_loss.detach(), g_loss=g_loss.detach(), l1=l1.detach(), l2=l2.detach(),
                     codebook_loss=codebook_loss.detach(), loss=loss.detach())
+
+    # ---- checkpoints in the reference's format (trainers/utils/base_trainer.py:92-115)
+    def save_ckpt(self, path, config=None):
+        """{'step', 'state_dict', 'config'} with the generator's state_dict under the reference's key
+        names, so either side can load the other's file (models/model_factory.py:14-17)."""
+        ckpt = {"step": self.global_step,
+                "state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
+                "config": config}
+        torch.save(ckpt, path)
+
+    def resume_from_checkpoint(self, path):
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        self.global_step = int(ckpt["step"])
+        self.model.load_state_dict(ckpt["state_dict"])
+        self.g_red.broadcast_parameters()
+        return ckpt.get("config")

@@ -143,3 +143,31 @@ def test_discriminator_conv_second_order_matches_nn_conv2d():
     assert len(ga) == len(gb)
     for a, b in zip(ga, gb):
         assert float((a - b).abs().max()) <= 1e-9 * max(1.0, float(b.abs().max()))
+
+
+def test_checkpoint_format_round_trip(tmp_path):
+    """save_ckpt writes the reference's {'step','state_dict','config'} file; model_factory.load_model
+    and resume_from_checkpoint read it back (trainers/utils/base_trainer.py:92-115)."""
+    from amk.models import ViTVQGAN
+    from amk.models.discriminator import NLayerDiscriminator
+    from amk.models.model_factory import load_model
+    from amk.train import VQGANTrainStep
+
+    vit = dict(dim=64, img_size=32, patch_size=8, n_heads=1, d_head=64, depth=1, mlp_dim=128, dropout=0.0)
+    cb = dict(codebook_size=64, codebook_dim=32)
+    torch.manual_seed(1)
+    tr = VQGANTrainStep(ViTVQGAN(vit, cb), NLayerDiscriminator(3, 8, 3))
+    tr.global_step = 37
+    path = str(tmp_path / "vitvqgan.pt")
+    tr.save_ckpt(path, config={"model": {"name": "vitvqgan"}})
+    raw = torch.load(path, weights_only=True)
+    assert set(raw) == {"step", "state_dict", "config"} and raw["step"] == 37
+    assert "encoder.encoder.layers.0.self_attn.q.0.weight" in raw["state_dict"]
+    assert "codebook.embedding.weight" in raw["state_dict"]
+    torch.manual_seed(2)
+    other = ViTVQGAN(vit, cb)
+    load_model(other, path)
+    for (n, a), b in zip(tr.model.state_dict().items(), other.state_dict().values()):
+        assert torch.equal(a, b), n
+    tr2 = VQGANTrainStep(ViTVQGAN(vit, cb), NLayerDiscriminator(3, 8, 3))
+    assert tr2.resume_from_checkpoint(path) == {"model": {"name": "vitvqgan"}} and tr2.global_step == 37
