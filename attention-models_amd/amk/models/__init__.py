@@ -7,6 +7,7 @@ from .muse import MUSE, BidirectionalDecoder
 from .vit import ViT
 from .vit_moe import ViTMoE
 from .vitvqgan import Codebook, ViTVQGAN
+from . import vqgan  # conv-VQGAN codebook (models/vqgan.py:138-182): vqgan.Codebook
 
 __all__ = ["SoftmaxAttention", "AgentAttention", "SwitchHeadAttention", "MoELayer", "Codebook", "ViTVQGAN",
            "ViT", "ViTMoE", "MUSE", "BidirectionalDecoder", "build_model"]

@@ -28,7 +28,8 @@
 namespace amk_vq {
 
 constexpr int ROWS_WG = 128;   // z rows per workgroup in vq_argmin (4 waves x 32)
-constexpr int CODES_LDS = 128; // codes staged per LDS tile (4 MFMA tiles of 32)
+// codes staged per LDS tile: 4 MFMA tiles of 32 up to C = 64, fewer for wide codes (tile <= 36 KB)
+template <int C> constexpr int codes_lds() { return C <= 64 ? 128 : (C == 128 ? 64 : 32); }
 constexpr int FIN_ROWS = 16;   // z rows per workgroup in vq_finalize
 constexpr float EPS = 1e-12f;  // F.normalize default eps
 
@@ -64,11 +65,12 @@ __global__ __launch_bounds__(256) void vq_prep_codebook_kernel(const float* __re
 
 // ---------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(256, 2) void vq_argmin_kernel(const float* __restrict__ z, const float* __restrict__ en,
+__global__ __launch_bounds__(256, (C <= 64 ? 2 : 1)) void vq_argmin_kernel(const float* __restrict__ z, const float* __restrict__ en,
                                                           const float* __restrict__ ee, int64_t N, int K, int nsplit,
                                                           float* __restrict__ zn_out, float* __restrict__ pmin,
                                                           int32_t* __restrict__ pidx) {
   constexpr int HC = C / 2;       // k-extent owned by one half-wave
+  constexpr int CODES_LDS = codes_lds<C>();
   constexpr int LS = C + 4;       // LDS row stride: conflict-free ds_read_b128 row reads
   __shared__ __attribute__((aligned(16))) float smem[CODES_LDS * LS + CODES_LDS];
   float* Es = smem;
@@ -319,6 +321,59 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ z
 }
 
 // ---------------------------------------------------------------------------------------
+// Same gradient for wide codes (C = 128, 256): C/4 lanes per row, 16 bytes per lane.
+template <int C>
+__global__ __launch_bounds__(256) void vq_bwd_wide_kernel(const float* __restrict__ z, const float* __restrict__ E,
+                                                          const float* __restrict__ zn, const float* __restrict__ zq,
+                                                          const int64_t* __restrict__ idx, const float* __restrict__ g_out,
+                                                          const float* __restrict__ g_loss, float beta, int64_t N,
+                                                          float* __restrict__ dz, float* __restrict__ dE) {
+  constexpr int LPR = C / 4;
+  const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
+  const int c = (threadIdx.x % LPR) * 4;
+  const bool valid = row < N;
+  const int64_t off = valid ? row * C + c : 0;
+  const int64_t code = valid ? idx[row] : 0;
+  const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 zr = valid ? ld4(z + off) : zero, er = valid ? ld4(E + code * C + c) : zero;
+  const float4 znv = valid ? ld4(zn + off) : zero, zqv = valid ? ld4(zq + off) : zero;
+  const float4 go = valid ? ld4(g_out + off) : zero;
+  const float coef = g_loss[0] * 2.f / (float)((double)N * C);
+  float dzn[4], dzq[4];
+  const float znA[4] = {znv.x, znv.y, znv.z, znv.w}, zqA[4] = {zqv.x, zqv.y, zqv.z, zqv.w};
+  const float goA[4] = {go.x, go.y, go.z, go.w};
+  float nz = zr.x * zr.x + zr.y * zr.y + zr.z * zr.z + zr.w * zr.w;
+  float ne = er.x * er.x + er.y * er.y + er.z * er.z + er.w * er.w;
+  float pz = 0.f, pq = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    dzn[e] = goA[e] + coef * beta * (znA[e] - zqA[e]);
+    dzq[e] = coef * (zqA[e] - znA[e]);
+    pz += znA[e] * dzn[e];
+    pq += zqA[e] * dzq[e];
+  }
+#pragma unroll
+  for (int o = LPR / 2; o >= 1; o >>= 1) {
+    nz += __shfl_xor(nz, o, 64);
+    ne += __shfl_xor(ne, o, 64);
+    pz += __shfl_xor(pz, o, 64);
+    pq += __shfl_xor(pq, o, 64);
+  }
+  nz = sqrtf(nz);
+  ne = sqrtf(ne);
+  if (valid) {
+    float gz[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      gz[e] = (nz > EPS) ? (dzn[e] - znA[e] * pz) / nz : dzn[e] / EPS;
+      const float ge = (ne > EPS) ? (dzq[e] - zqA[e] * pq) / ne : dzq[e] / EPS;
+      atomicAdd(dE + code * C + c + e, ge);
+    }
+    st4(dz + off, make_float4(gz[0], gz[1], gz[2], gz[3]));
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void vq_gather_kernel(const int64_t* __restrict__ idx, const float* __restrict__ E,
                                                         int64_t N, float* __restrict__ out) {
@@ -363,14 +418,16 @@ extern "C" int amk_vq_lookup_fwd(const float* z, const float* codebook, int64_t 
   AMK_CHECK_ARG(z && codebook && en_ws && ee_ws && pmin_ws && pidx_ws && idx && out && zq && zn && sqerr_partial,
                 "amk_vq_lookup_fwd: null pointer");
   AMK_CHECK_ARG(N > 0 && K > 0 && nsplit > 0, "amk_vq_lookup_fwd: non-positive size N=%lld K=%d nsplit=%d", (long long)N, K, nsplit);
-  AMK_CHECK_SUPPORTED(C == 32 || C == 64, "amk_vq_lookup_fwd: codebook_dim %d not supported (32 or 64)", C);
+  AMK_CHECK_SUPPORTED(C == 32 || C == 64 || C == 128 || C == 256, "amk_vq_lookup_fwd: codebook_dim %d not supported (32, 64, 128, 256)", C);
   AMK_CHECK_SUPPORTED(K % (32 * nsplit) == 0, "amk_vq_lookup_fwd: K=%d must be a multiple of 32*nsplit=%d", K, 32 * nsplit);
   AMK_CHECK_ARG(a16(z) && a16(codebook) && a16(en_ws) && a16(out) && a16(zq) && a16(zn), "amk_vq_lookup_fwd: pointers must be 16-byte aligned");
   const int64_t nwg = ((N + ROWS_WG - 1) / ROWS_WG) * nsplit;
   AMK_CHECK_SUPPORTED(nwg < (1ll << 31) && (N + FIN_ROWS - 1) / FIN_ROWS < (1ll << 31), "amk_vq_lookup_fwd: grid too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 32) launch_fwd<32>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
-  else launch_fwd<64>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  else if (C == 64) launch_fwd<64>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  else if (C == 128) launch_fwd<128>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  else launch_fwd<256>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
   AMK_CHECK_LAUNCH("amk_vq_lookup_fwd");
   return AMK_OK;
 }
@@ -380,19 +437,24 @@ extern "C" int amk_vq_lookup_bwd(const float* z, const float* codebook, const fl
                                  int64_t N, int K, int C, float* dz, float* dcodebook, void* stream) {
   AMK_CHECK_ARG(z && codebook && zn && zq && idx && g_out && g_loss && dz && dcodebook, "amk_vq_lookup_bwd: null pointer");
   AMK_CHECK_ARG(N > 0 && K > 0, "amk_vq_lookup_bwd: non-positive size");
-  AMK_CHECK_SUPPORTED(C == 32 || C == 64, "amk_vq_lookup_bwd: codebook_dim %d not supported (32 or 64)", C);
+  AMK_CHECK_SUPPORTED(C == 32 || C == 64 || C == 128 || C == 256, "amk_vq_lookup_bwd: codebook_dim %d not supported (32, 64, 128, 256)", C);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(dcodebook, 0, (size_t)K * C * sizeof(float), st) != hipSuccess) {
     amk_set_error("amk_vq_lookup_bwd: hipMemsetAsync failed");
     return AMK_ELAUNCH;
   }
-  const int rpb = 256 / C;
+  const int rpb = C <= 64 ? 256 / C : 256 / (C / 4);
   const int64_t nb = (N + rpb - 1) / rpb;
   AMK_CHECK_SUPPORTED(nb < (1ll << 31), "amk_vq_lookup_bwd: grid too large");
+  AMK_CHECK_ARG(C <= 64 || (a16(z) && a16(codebook) && a16(zn) && a16(zq) && a16(g_out) && a16(dz)), "amk_vq_lookup_bwd: pointers must be 16-byte aligned");
   if (C == 32)
     hipLaunchKernelGGL(vq_bwd_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
-  else
+  else if (C == 64)
     hipLaunchKernelGGL(vq_bwd_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
+  else if (C == 128)
+    hipLaunchKernelGGL(vq_bwd_wide_kernel<128>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
+  else
+    hipLaunchKernelGGL(vq_bwd_wide_kernel<256>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
   AMK_CHECK_LAUNCH("amk_vq_lookup_bwd");
   return AMK_OK;
 }
@@ -400,13 +462,15 @@ extern "C" int amk_vq_lookup_bwd(const float* z, const float* codebook, const fl
 extern "C" int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, int C, float* out, void* stream) {
   AMK_CHECK_ARG(idx && codebook && out, "amk_vq_gather: null pointer");
   AMK_CHECK_ARG(N > 0 && K > 0, "amk_vq_gather: non-positive size");
-  AMK_CHECK_SUPPORTED(C == 32 || C == 64, "amk_vq_gather: codebook_dim %d not supported (32 or 64)", C);
+  AMK_CHECK_SUPPORTED(C == 32 || C == 64 || C == 128 || C == 256, "amk_vq_gather: codebook_dim %d not supported (32, 64, 128, 256)", C);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpb = 256 / (C / 4);
   const int64_t nb = (N + rpb - 1) / rpb;
   AMK_CHECK_SUPPORTED(nb < (1ll << 31), "amk_vq_gather: grid too large");
   if (C == 32) hipLaunchKernelGGL(vq_gather_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
-  else hipLaunchKernelGGL(vq_gather_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
+  else if (C == 64) hipLaunchKernelGGL(vq_gather_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
+  else if (C == 128) hipLaunchKernelGGL(vq_gather_kernel<128>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
+  else hipLaunchKernelGGL(vq_gather_kernel<256>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
   AMK_CHECK_LAUNCH("amk_vq_gather");
   return AMK_OK;
 }

@@ -37,7 +37,7 @@ def load_reference():
     sys.modules["models"] = pkg
     mods = {}
     for name in ("softmax_attention", "agent_attention", "switchhead_attention", "moe", "vitvqgan", "positional_encoding",
-                 "transformer", "vit"):
+                 "transformer", "vit", "vqgan"):
         mods[name] = importlib.import_module(f"models.{name}")
     pkg.SwitchHeadAttention = mods["switchhead_attention"].SwitchHeadAttention
     pkg.MoELayer = mods["moe"].MoELayer
@@ -173,6 +173,32 @@ def gen_codebook(mods, meta):
         "codebook_c3", idx=idx.numpy().astype(np.int16), loss=loss.numpy(), margin=margin.astype(np.float32),
         zq_sum=zq.double().sum().numpy(), dims=np.array([K, C, B, T]), seeds=np.array([311, 312])),
         ref_cpu_ms_fwd=ms, min_margin=float(margin.min()))
+
+
+def gen_vqgan_codebook(mods, meta):
+    """Conv-VQGAN codebook (models/vqgan.py:138-182): (B, C, H, W) layout, C = 256 (README.md:246-249),
+    beta on the codebook term, indices_to_embeddings without the l2-norm."""
+    CB = mods["vqgan"].Codebook
+    K, C, B, H = 512, 256, 2, 4
+    cb = CB(K, C)
+    with torch.no_grad():
+        cb.embedding.weight.copy_(seeded((K, C), 331))
+    z = seeded((B, C, H, H), 332).requires_grad_(True)
+    cot = seeded((B, C, H, H), 333)
+    zq, idx, loss = cb(z)
+    gz, gE = torch.autograd.grad((zq * cot).sum() + 3.0 * loss, [z, cb.embedding.weight])
+    with torch.no_grad():
+        zf = F.normalize(z.permute(0, 2, 3, 1), dim=-1).reshape(-1, C)
+        en = F.normalize(cb.embedding.weight, dim=-1)
+        dist = zf.pow(2).sum(1, keepdim=True) + en.pow(2).sum(1) - 2 * zf @ en.t()
+        two = torch.topk(dist, 2, dim=1, largest=False).values
+        margin = (two[:, 1] - two[:, 0]).numpy()
+        emb = cb.indices_to_embeddings(idx.view(B, H * H))
+    meta["vqgan_codebook"] = dict(bytes=save(
+        "vqgan_codebook", E=cb.embedding.weight.detach().numpy(), z=z.detach().numpy(), cot=cot.numpy(),
+        zq=zq.detach().numpy(), idx=idx.numpy(), loss=loss.detach().numpy(), gz=gz.numpy(), gE=gE.numpy(),
+        margin=margin, emb=emb.detach().numpy(), loss_weight=np.array(3.0), beta=np.array(cb.beta)),
+        min_margin=float(margin.min()))
 
 
 class _SwiGLU(nn.Module):
@@ -380,8 +406,17 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(os.cpu_count() or 1)
     mods = load_reference()
+    meta_path = os.path.join(OUT, "golden_meta.json")
+    if len(sys.argv) > 2 and sys.argv[1] == "--only":   # add / refresh single fixtures, keep the rest
+        meta = json.load(open(meta_path))
+        for name in sys.argv[2:]:
+            globals()["gen_" + name](mods, meta)
+        with open(meta_path, "w") as f:
+            json.dump(meta, f, indent=1, sort_keys=True)
+        return
     meta = dict(torch=torch.__version__, threads=torch.get_num_threads(), cpu_count=os.cpu_count(),
                 reference=REF, generated_by="oracle/gen_golden.py")
+    gen_vqgan_codebook(mods, meta)
     gen_softmax_attention(mods, meta)
     gen_codebook(mods, meta)
     gen_vitvqgan(mods, meta)

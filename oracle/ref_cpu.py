@@ -185,6 +185,25 @@ def indices_to_embeddings(idx, codebook):
     return l2norm(codebook[idx])
 
 
+def vqgan_codebook_forward(z_bchw, codebook, beta=0.25):
+    """Conv-VQGAN Codebook.forward (models/vqgan.py:148-176): channels-first input, the same normalised
+    nearest-neighbour lookup, but beta weighs the CODEBOOK term and the indices come back flat (B*H*W)."""
+    z = l2norm(z_bchw.permute(0, 2, 3, 1))
+    d = codebook_distances(z, codebook)
+    idx = torch.argmin(d, dim=1)
+    zq = l2norm(codebook[idx]).view(z.shape)
+    loss = torch.mean((zq.detach() - z) ** 2) + beta * torch.mean((zq - z.detach()) ** 2)
+    out = z + (zq - z).detach()
+    return out.permute(0, 3, 1, 2), idx, loss
+
+
+def vqgan_indices_to_embeddings(idx_bt, codebook):
+    """models/vqgan.py:178-182: raw (un-normalised) rows, 'b (h w) d -> b d h w' with h = w = sqrt(T)."""
+    e = codebook[idx_bt]
+    side = int(e.shape[1] ** 0.5)
+    return e.view(e.shape[0], side, side, -1).permute(0, 3, 1, 2)
+
+
 # ------------------------------------------------------------------ ViT-VQGAN scaffolding
 def _ln(x, w, prefix):
     return F.layer_norm(x, x.shape[-1:], w[prefix + ".weight"], w[prefix + ".bias"])

@@ -232,3 +232,20 @@ def test_muse_decoder_small_matches_reference(variant):
     assert_close(gs[0], fx[f"{variant}:gctx"], 2e-5, "grad context")
     for n, g in zip(names, gs[1:]):
         assert_close(g, fx[f"{variant}:g:{n}"], 5e-5, f"grad {n}")
+
+
+def test_vqgan_codebook_oracle_matches_reference_fixture():
+    """oracle.vqgan_codebook_forward against the reference's conv-VQGAN Codebook (models/vqgan.py:138-182)."""
+    fx = load_golden("vqgan_codebook")
+    E = torch.from_numpy(fx["E"]).requires_grad_(True)
+    z = torch.from_numpy(fx["z"]).requires_grad_(True)
+    zq, idx, loss = ref_cpu.vqgan_codebook_forward(z, E, float(fx["beta"]))
+    assert torch.equal(idx, torch.from_numpy(fx["idx"]))
+    assert_close(zq, fx["zq"], 2e-6, "zq")
+    assert_close(loss, fx["loss"], 2e-6, "loss")
+    gz, gE = torch.autograd.grad((zq * torch.from_numpy(fx["cot"])).sum() + float(fx["loss_weight"]) * loss, [z, E])
+    assert_close(gz, fx["gz"], 2e-6, "gz")
+    assert_close(gE, fx["gE"], 2e-6, "gE")
+    B = z.shape[0]
+    emb = ref_cpu.vqgan_indices_to_embeddings(idx.view(B, -1), E.detach())
+    assert_close(emb, fx["emb"], 0.0, "emb")

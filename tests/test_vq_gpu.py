@@ -66,7 +66,8 @@ def test_codebook_config3_golden_indices(device):
     assert abs(float(zq.double().sum()) - float(fx["zq_sum"])) < 1e-2
 
 
-@pytest.mark.parametrize("N,K,C", [(1, 32, 32), (100, 64, 32), (129, 512, 64), (1000, 2048, 32), (4096, 8192, 32)])
+@pytest.mark.parametrize("N,K,C", [(1, 32, 32), (100, 64, 32), (129, 512, 64), (1000, 2048, 32), (4096, 8192, 32),
+                                   (300, 256, 128), (513, 1024, 256), (33, 32, 256)])
 def test_lookup_vs_oracle(device, N, K, C):
     from amk import ops
 
@@ -165,3 +166,27 @@ def test_vitvqgan_small_golden(device):
     for n, g in zip(names, gs):
         if "g:" + n in fx:
             assert_close(g, fx["g:" + n], 2e-4, f"grad {n}")
+
+
+def test_vqgan_codebook_golden(device):
+    """Conv-VQGAN codebook (models/vqgan.py:138-182; C = 256, channels-first, beta on the codebook term)
+    against the reference's own outputs."""
+    from amk.models.vqgan import Codebook
+
+    fx = load_golden("vqgan_codebook")
+    K, C = fx["E"].shape
+    cb = Codebook(K, C, beta=float(fx["beta"]))
+    cb.load_state_dict({"embedding.weight": torch.from_numpy(fx["E"])})
+    cb = cb.to(device)
+    z = torch.from_numpy(fx["z"]).to(device).requires_grad_(True)
+    cot = torch.from_numpy(fx["cot"]).to(device)
+    zq, idx, loss = cb(z)
+    assert idx.dtype == torch.int64 and tuple(idx.shape) == tuple(fx["idx"].shape)
+    assert _check_indices(idx, fx["idx"], fx["margin"]) == 0
+    assert_close(zq, fx["zq"], TOL, "z_q")
+    assert_close(loss, fx["loss"], TOL, "loss")
+    gz, gE = torch.autograd.grad((zq * cot).sum() + float(fx["loss_weight"]) * loss, [z, cb.embedding.weight])
+    assert_close(gz, fx["gz"], TOL, "grad z")
+    assert_close(gE, fx["gE"], TOL, "grad codebook")
+    emb = cb.indices_to_embeddings(idx.view(z.shape[0], -1))
+    assert_close(emb, fx["emb"], 0.0, "indices_to_embeddings")
