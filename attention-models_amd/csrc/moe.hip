@@ -92,24 +92,45 @@ __global__ __launch_bounds__(256) void route_local_kernel(const int64_t* __restr
   }
 }
 
-__global__ __launch_bounds__(256) void route_scan_kernel(int32_t* __restrict__ blockhist, int nblk, int E,
-                                                         int32_t* __restrict__ counts, int32_t* __restrict__ offsets) {
+// One wave per expert (16 waves, experts dealt round-robin): the per-block counts of an expert are
+// turned into exclusive bases 64 blocks at a time with a wave prefix sum (a serial walk over the
+// 260 blocks of a ViTMoE layer cost 60 us); wave 0 then scans the expert totals into offsets.
+__global__ __launch_bounds__(1024) void route_scan_kernel(int32_t* __restrict__ blockhist, int nblk, int E,
+                                                          int32_t* __restrict__ counts, int32_t* __restrict__ offsets) {
   __shared__ int total[1024];
-  for (int e = threadIdx.x; e < E; e += 256) {  // one thread per expert walks the blocks in order
-    int acc = 0;
-    for (int b = 0; b < nblk; ++b) {
-      const int c = blockhist[(int64_t)b * E + e];
-      blockhist[(int64_t)b * E + e] = acc;  // exclusive: base of this block inside the expert
-      acc += c;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int e = wave; e < E; e += 16) {
+    int running = 0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+      const int b = b0 + lane;
+      const int c = b < nblk ? blockhist[(int64_t)b * E + e] : 0;
+      int x = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+      if (b < nblk) blockhist[(int64_t)b * E + e] = running + x - c;  // exclusive: base of this block inside the expert
+      running += __shfl(x, 63, 64);
     }
-    counts[e] = acc;
-    total[e] = acc;
+    if (lane == 0) { counts[e] = running; total[e] = running; }
   }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    int acc = 0;
-    for (int e = 0; e < E; ++e) { offsets[e] = acc; acc += total[e]; }
-    offsets[E] = acc;
+  if (wave == 0) {
+    int running = 0;
+    for (int e0 = 0; e0 < E; e0 += 64) {
+      const int e = e0 + lane;
+      const int c = e < E ? total[e] : 0;
+      int x = c;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const int y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+      if (e < E) offsets[e] = running + x - c;
+      running += __shfl(x, 63, 64);
+    }
+    if (lane == 0) offsets[E] = running;
   }
 }
 
@@ -480,7 +501,7 @@ extern "C" int amk_moe_route(const float* logits, int64_t U, int E, int k,
   hipLaunchKernelGGL(route_topk_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, logits, U, E, k, ids, gate);
   const int nblk = (int)((P + 255) / 256);
   hipLaunchKernelGGL(route_local_kernel, dim3(nblk), dim3(256), 0, st, ids, P, E, rank, blockhist);
-  hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(256), 0, st, blockhist, nblk, E, counts, offsets);
+  hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, st, blockhist, nblk, E, counts, offsets);
   hipLaunchKernelGGL(route_perm_kernel, dim3(nblk), dim3(256), 0, st, ids, offsets, blockhist, rank, P, E, perm);
   AMK_CHECK_LAUNCH("amk_moe_route");
   return AMK_OK;
