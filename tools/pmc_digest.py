@@ -1,0 +1,74 @@
+"""Fold the four rocprofv3 --pmc passes (tools/README.md) into profiles/rNN_pmc_kernels_bB.json.
+
+    python tools/pmc_digest.py --sq A.csv --fetch B.csv --write C.csv --atomic D.csv --batch 32 --out profiles/r01_pmc_kernels_b32.json
+
+Per kernel (amk_* kernels only; averages over the launches of a pass):
+  hbm_bytes_per_launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024   (FETCH_SIZE / WRITE_SIZE are KiB; gfx950 reports
+                         half of a wide coalesced read stream, MI355X_MICROARCH.md)
+  atomic bytes         = TCC_EA0_ATOMIC_sum * 64
+  clock_GHz            = GRBM_GUI_ACTIVE / duration          (GRBM_GUI_ACTIVE sums the 8 XCDs: / 8)
+  mfma_busy_frac       = SQ_VALU_MFMA_BUSY_CYCLES / (4 * 256 * cycles)   (per SIMD)
+  valu_per_mfma        = SQ_INSTS_VALU / SQ_INSTS_MFMA
+"""
+import argparse
+import csv
+import json
+import re
+from collections import defaultdict
+
+
+def short(name):
+    m = re.search(r"(\w+_kernel)", name)
+    return m.group(1) if m else name
+
+
+def fold(path):
+    acc = defaultdict(lambda: defaultdict(list))
+    dur = defaultdict(list)
+    seen = set()
+    for r in csv.DictReader(open(path)):
+        if "amk_" not in r["Kernel_Name"]:
+            continue
+        k = short(r["Kernel_Name"])
+        acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    return {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}, {k: sum(v) / len(v) for k, v in dur.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    for n in ("sq", "fetch", "write", "atomic", "out"):
+        ap.add_argument("--" + n, required=True)
+    ap.add_argument("--batch", type=int, required=True)
+    ap.add_argument("--about", default="")
+    a = ap.parse_args()
+    sq, dur = fold(a.sq)
+    out = {}
+    for k, c in sq.items():
+        d = dict(c)
+        for path, key, name in ((a.fetch, "FETCH_SIZE", "FETCH_SIZE_KiB"), (a.write, "WRITE_SIZE", "WRITE_SIZE_KiB"),
+                                (a.atomic, "TCC_EA0_ATOMIC_sum", "TCC_EA0_ATOMIC_sum")):
+            vals, _ = fold(path)
+            d[name] = vals.get(k, {}).get(key, 0.0)
+        d["hbm_bytes_per_launch"] = (2 * d["FETCH_SIZE_KiB"] + d["WRITE_SIZE_KiB"]) * 1024
+        d["avg_us_profiled"] = dur[k]
+        cycles = d.get("GRBM_GUI_ACTIVE", 0.0) / 8
+        if cycles:
+            d["clock_GHz"] = cycles / (dur[k] * 1e3)
+            if d.get("SQ_INSTS_MFMA"):
+                d["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cycles)
+                d["valu_per_mfma"] = d["SQ_INSTS_VALU"] / d["SQ_INSTS_MFMA"]
+        out[k] = d
+    about = a.about or ("rocprofv3 --pmc passes over `python tools/kbench.py --batch %d --iters 5` on one MI355X; separate passes "
+                        "(SQ+GRBM set, FETCH_SIZE, WRITE_SIZE, TCC_EA0_ATOMIC_sum) as MI355X_MICROARCH.md prescribes; folded by "
+                        "tools/pmc_digest.py" % a.batch)
+    json.dump({"_about": about, "batch": a.batch, "kernels": out}, open(a.out, "w"), indent=1)
+    for k, d in sorted(out.items()):
+        print(f"{k:28s} {d['avg_us_profiled']:9.1f} us  hbm {d['hbm_bytes_per_launch']/1e6:8.1f} MB  clock {d.get('clock_GHz', 0):.2f} GHz"
+              f"  mfma busy {d.get('mfma_busy_frac', 0):.2f}  valu/mfma {d.get('valu_per_mfma', 0):.2f}")
+
+
+if __name__ == "__main__":
+    main()
