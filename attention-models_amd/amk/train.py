@@ -43,14 +43,23 @@ class VQGANTrainStep:
     def __init__(self, model, discr, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0,
                  adv_loss_weight=0.1, logit_laplace_weight=1.0, max_grad_norm=1.0,
                  warmup_steps=50000, decay_steps=100000, gp_lambda=10.0, bucket_bytes=32 << 20,
-                 share_forward=False):
+                 share_forward=False, capturable=False):
         self.model, self.discr = model, discr
         self.adv_w, self.laplace_w = adv_loss_weight, logit_laplace_weight
         self.max_grad_norm, self.gp_lambda = max_grad_norm, gp_lambda
         self.base_lr, self.warmup_steps, self.decay_steps = lr, warmup_steps, decay_steps
         fused = next(model.parameters()).is_cuda
-        self.g_optim = torch.optim.Adam(model.parameters(), lr=lr, betas=betas, weight_decay=weight_decay, fused=fused)
-        self.d_optim = torch.optim.Adam(discr.parameters(), lr=lr, betas=betas, weight_decay=weight_decay, fused=fused)
+        # capturable=True: the learning rate lives in a device tensor and the optimizer never reads
+        # device state on the host, so step_body() can be captured into a HIP graph (amk/graphs.py)
+        okw = dict(betas=betas, weight_decay=weight_decay, fused=fused)
+        if capturable:
+            dev = next(model.parameters()).device
+            okw.update(capturable=True)
+            self.g_optim = torch.optim.Adam(model.parameters(), lr=torch.tensor(float(lr), device=dev), **okw)
+            self.d_optim = torch.optim.Adam(discr.parameters(), lr=torch.tensor(float(lr), device=dev), **okw)
+        else:
+            self.g_optim = torch.optim.Adam(model.parameters(), lr=lr, **okw)
+            self.d_optim = torch.optim.Adam(discr.parameters(), lr=lr, **okw)
         self.g_red = GradReducer(model.parameters(), bucket_bytes)
         self.d_red = GradReducer(discr.parameters(), bucket_bytes)
         self.g_red.broadcast_parameters()
@@ -78,11 +87,20 @@ class VQGANTrainStep:
         lr = cosine_warmup_lr(self.global_step, self.base_lr, self.decay_steps, self.warmup_steps)
         for opt in (self.g_optim, self.d_optim):
             for g in opt.param_groups:
-                g["lr"] = lr
+                if torch.is_tensor(g["lr"]):
+                    g["lr"].fill_(lr)
+                else:
+                    g["lr"] = lr
 
     def step(self, img, sync=True):
-        model, discr = self.model, self.discr
         self._set_lr()
+        logs = self.step_body(img, sync)
+        self.global_step += 1
+        return logs
+
+    def step_body(self, img, sync=True):
+        """Everything of a step that runs on the device (no host-side schedule): what a HIP graph captures."""
+        model, discr = self.model, self.discr
         # ---- discriminator phase (reference :146-163)
         shared = None
         if self.share_forward:
@@ -119,7 +137,6 @@ class VQGANTrainStep:
                 torch.nn.utils.clip_grad_norm_(model.parameters(), self.max_grad_norm)
             self.g_optim.step()
             self.g_red.zero_grad()
-        self.global_step += 1
         return dict(d_loss=d_loss.detach(), g_loss=g_loss.detach(), l1=l1.detach(), l2=l2.detach(),
                     codebook_loss=codebook_loss.detach(), loss=loss.detach())
 

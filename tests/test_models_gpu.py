@@ -233,3 +233,38 @@ def test_train_step_shared_forward_is_the_same_step(device):
         assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), n
     for (n, p), q in zip(discr.named_parameters(), discr2.parameters()):
         assert float((p - q).abs().max()) <= 1e-6 * max(1.0, float(p.abs().max())), n
+
+
+def test_vqgan_step_body_replays_as_hip_graph(device):
+    """The whole GAN step (both phases, gradient penalty's double backward, MIOpen convolutions, fused
+    Adam, clip) is capture-safe: two replays of the captured step_body = two eager steps.
+    gp_lambda = 0 so that the penalty's random eta (a different Philox offset under capture) does not
+    enter the comparison."""
+    import copy
+
+    from amk.graphs import GraphedStep
+    from amk.models import ViTVQGAN
+    from amk.models.discriminator import NLayerDiscriminator
+    from amk.train import VQGANTrainStep
+
+    vit = dict(dim=64, img_size=32, patch_size=8, n_heads=1, d_head=64, depth=1, mlp_dim=128, dropout=0.0)
+    torch.manual_seed(0)
+    model = ViTVQGAN(vit, dict(codebook_size=64, codebook_dim=32)).to(device)
+    discr = NLayerDiscriminator(3, 8, 3).to(device)
+    model2, discr2 = copy.deepcopy(model), copy.deepcopy(discr)
+    imgs = torch.rand(4, 3, 32, 32, device=device)
+    eager = VQGANTrainStep(model, discr, warmup_steps=1, gp_lambda=0.0, capturable=True)
+    graphed = VQGANTrainStep(model2, discr2, warmup_steps=1, gp_lambda=0.0, capturable=True)
+    graphed._set_lr()
+    g = GraphedStep(lambda x: graphed.step_body(x), [imgs], warmup=1)   # runs one eager step, then captures
+    graphed.global_step = 1
+    eager.step(imgs)                                                     # the same one step
+    for _ in range(2):
+        le = eager.step(imgs)
+        graphed._set_lr()
+        lg = g.replay(imgs)
+        graphed.global_step += 1
+        for k in le:
+            assert float((le[k] - lg[k]).abs()) <= 2e-5 * max(1.0, float(le[k].abs())), k
+    for (n, p), q in zip(model.named_parameters(), model2.parameters()):
+        assert float((p - q).abs().max()) <= 2e-5 * max(1.0, float(p.abs().max())), n
