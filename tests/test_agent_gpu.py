@@ -72,3 +72,32 @@ def test_agent_vs_oracle(device, B, T, dim, h, agent_num):
         if n in ("bias1", "bias2"):
             continue
         _abs_close(params[n].grad, g, TOL, f"grad {n}")
+
+
+def test_agent_full_size_properties(device):
+    """B 64, T 1024, h 6 (the chip-filling case, 3072 workgroups per kernel): (1) one batch element
+    equals the same element run alone (chunks / workgroups do not leak into each other);
+    (2) forward and backward are bitwise reproducible (partials are folded in chunk order, no atomics);
+    (3) one element against the CPU oracle."""
+    from amk.models import AgentAttention
+
+    torch.manual_seed(0)
+    m = AgentAttention(384, 6, 64).to(device)
+    x = torch.randn(64, 1024, 384, device=device, requires_grad=True)
+    cot = torch.randn(64, 1024, 384, device=device)
+    out = m(x)
+    (g,) = torch.autograd.grad((out * cot).sum(), [x])
+    out2 = m(x)
+    (g2,) = torch.autograd.grad((out2 * cot).sum(), [x])
+    assert torch.equal(out, out2) and torch.equal(g, g2)
+    xs = x[17:18].detach().clone().requires_grad_(True)
+    outs = m(xs)
+    (gs,) = torch.autograd.grad((outs * cot[17:18]).sum(), [xs])
+    assert_close(outs, out[17:18], 1e-6, "element alone vs in batch")
+    assert_close(gs, g[17:18], 1e-6, "grad: element alone vs in batch")
+    w = {n: p.detach().cpu() for n, p in m.named_parameters()}
+    xr = x[17:18].detach().cpu().requires_grad_(True)
+    out_r = ref_cpu.agent_attention(xr, w, 6, 64, 47)
+    (g_r,) = torch.autograd.grad((out_r * cot[17:18].cpu()).sum(), [xr])
+    assert_close(out[17:18], out_r, TOL, "vs oracle")
+    assert_close(g[17:18], g_r, TOL, "grad vs oracle")
