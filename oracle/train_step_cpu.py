@@ -56,9 +56,9 @@ def host_cores():
     return n
 
 
-def time_train_step(state_dict, cfg, discr, batch=2, steps=2, warmup=1, threads=None, budget_s=30.0):
+def time_train_step(state_dict, cfg, discr, batch=2, steps=8, warmup=1, threads=None, budget_s=15.0):
     """Returns (images_per_sec, threads_used, description of the sample).  The sample is
-    bounded: if the warm-up step alone shows `steps` would exceed budget_s, fewer are timed."""
+    bounded to about `budget_s` seconds of CPU work: the warm-up step sets how many of `steps` are timed."""
     threads = threads or min(host_cores(), 32)
     torch.set_num_threads(threads)
     w = {k: v.detach().clone().float().cpu() for k, v in state_dict.items()}
