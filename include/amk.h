@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 100 /* 0.1.0 */
+#define AMK_VERSION 110 /* 0.1.10: agent workspace arguments, layernorm / colsum entry points, codebook_dim 128 / 256 */
 
 enum {
   AMK_OK = 0,
