@@ -130,13 +130,16 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
   const float* kc_col = &Kc[(32 * kg) * LDS_STRIDE + dcol0 + c16];       // B: K[32*kg + s][dcol]
 
   const int ntile = (p.I + TQ - 1) / TQ;
+  // Two barriers per query tile.  After the dS barrier every wave is past the phases that read the
+  // q / dO / stats tiles, so the next tile is committed there -- under the dQ product, which only
+  // reads dS and K -- and the barrier that closes the dQ product also publishes it.
   prefetch(0);
+  __syncthreads();  // the K block is in LDS
+  commit();
+  __syncthreads();
+  if (ntile > 1) prefetch(TQ);
   for (int t = 0; t < ntile; ++t) {
     const int i0 = t * TQ;
-    __syncthreads();  // previous tile fully consumed (q/dO tiles, dS tile)
-    commit();
-    __syncthreads();
-    if (t + 1 < ntile) prefetch(i0 + TQ);
 
     // ---- S and dP for the tile's 32 queries x this wave's 32 keys (2 x 32 MFMAs)
     f32x16 s = zero16(), dp = zero16();
@@ -202,7 +205,11 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
       dk0 = mfma32(qc[0], dp[r], dk0);
       dk1 = mfma32(qc[32], dp[r], dk1);
     }
-    __syncthreads();  // every wave's dS columns are in LDS
+    __syncthreads();  // every wave's dS columns are in LDS; the q / dO / stats tiles are dead
+    if (t + 1 < ntile) {
+      commit();
+      if (t + 2 < ntile) prefetch(i0 + 2 * TQ);
+    }
 
     // ---- dQ (16 queries x 32 columns per wave) = dS (16 x 128) K (128 x 32): 64 MFMAs 16x16x4
     f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
@@ -235,6 +242,7 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
         }
       }
     }
+    __syncthreads();  // dS consumed, the next q / dO tiles visible
   }
 
   if (kvalid) {
