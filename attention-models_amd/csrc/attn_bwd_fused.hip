@@ -133,13 +133,24 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
   // Two barriers per query tile.  After the dS barrier every wave is past the phases that read the
   // q / dO / stats tiles, so the next tile is committed there -- under the dQ product, which only
   // reads dS and K -- and the barrier that closes the dQ product also publishes it.
-  prefetch(0);
+  // Co-resident workgroups start at different query tiles (the order of the dQ atomics and of the
+  // dK / dV accumulation does not matter): it keeps their MFMA and barrier phases from lining up.
+  const int rot = (int)((blockIdx.x * 5u) % (unsigned)ntile);
+  auto tile_of = [&](int t) { const int x = t + rot; return x >= ntile ? x - ntile : x; };
+  qload.seek(rot, p.qs.st, tid);
+  gload.seek(rot, p.dos.st, tid);
+  prefetch(rot * TQ);
   __syncthreads();  // the K block is in LDS
   commit();
   __syncthreads();
-  if (ntile > 1) prefetch(TQ);
+  if (ntile > 1) {
+    const int nx = tile_of(1);
+    qload.seek(nx, p.qs.st, tid);
+    gload.seek(nx, p.dos.st, tid);
+    prefetch(nx * TQ);
+  }
   for (int t = 0; t < ntile; ++t) {
-    const int i0 = t * TQ;
+    const int i0 = tile_of(t) * TQ;
 
     // ---- S and dP for the tile's 32 queries x this wave's 32 keys (2 x 32 MFMAs)
     f32x16 s = zero16(), dp = zero16();
@@ -208,7 +219,12 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
     __syncthreads();  // every wave's dS columns are in LDS; the q / dO / stats tiles are dead
     if (t + 1 < ntile) {
       commit();
-      if (t + 2 < ntile) prefetch(i0 + 2 * TQ);
+      if (t + 2 < ntile) {
+        const int nx = tile_of(t + 2);
+        qload.seek(nx, p.qs.st, tid);
+        gload.seek(nx, p.dos.st, tid);
+        prefetch(nx * TQ);
+      }
     }
 
     // ---- dQ (16 queries x 32 columns per wave) = dS (16 x 128) K (128 x 32): 64 MFMAs 16x16x4

@@ -87,6 +87,12 @@ struct RowStagerT {
       voff[ps] += step;
     }
   }
+  // jump so that the next load() fetches row block `blk` (blocks of ROWS rows)
+  __device__ __forceinline__ void seek(int blk, int64_t row_stride, int tid) {
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+#pragma unroll
+    for (int ps = 0; ps < NP; ++ps) voff[ps] = (int)(((int64_t)(srow + 16 * ps) * row_stride + scol) * 4) + blk * step;
+  }
 };
 typedef RowStagerT<TILE> RowStager;
 
