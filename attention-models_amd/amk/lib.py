@@ -41,6 +41,8 @@ SIGNATURES = {
     "amk_colsum": (_I, [_P, _L, _I, _P, _P]),
     "amk_swiglu_fwd": (_I, [_P, _L, _I, _P, _P]),
     "amk_swiglu_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
+    "amk_geglu_fwd": (_I, [_P, _L, _I, _P, _P]),
+    "amk_geglu_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
     "amk_moe_route_ws_ints": (_L, [_L, _I, _I]),
     "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 8),
     "amk_grouped_gemm_nt": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),

@@ -486,33 +486,44 @@ def agent_attention(qkv2, conv_w, conv_b, num_heads, dim_head, pool, scale):
 
 # ---------------------------------------------------------------------------- SwiGLU gate
 class _SwiGLU(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, ab):
+    FWD, BWD = "amk_swiglu_fwd", "amk_swiglu_bwd"
+
+    @classmethod
+    def forward(cls, ctx, ab):
         _require_device(ab)
         H = ab.shape[-1] // 2
         ab2 = ab.contiguous().view(-1, 2 * H)
         M = ab2.shape[0]
         out = torch.empty((M, H), device=ab.device, dtype=torch.float32)
         L = _lib.load()
-        _lib.check(L.amk_swiglu_fwd(_ptr(ab2), M, H, _ptr(out), _stream()), "amk_swiglu_fwd")
+        _lib.check(getattr(L, cls.FWD)(_ptr(ab2), M, H, _ptr(out), _stream()), cls.FWD)
         ctx.save_for_backward(ab2)
         ctx.shape = ab.shape
         return out.view(*ab.shape[:-1], H)
 
-    @staticmethod
-    def backward(ctx, d_out):
+    @classmethod
+    def backward(cls, ctx, d_out):
         (ab2,) = ctx.saved_tensors
         M, H2 = ab2.shape
         d_out = d_out.contiguous().view(M, H2 // 2)
         d_ab = torch.empty_like(ab2)
         L = _lib.load()
-        _lib.check(L.amk_swiglu_bwd(_ptr(ab2), _ptr(d_out), M, H2 // 2, _ptr(d_ab), _stream()), "amk_swiglu_bwd")
+        _lib.check(getattr(L, cls.BWD)(_ptr(ab2), _ptr(d_out), M, H2 // 2, _ptr(d_ab), _stream()), cls.BWD)
         return d_ab.view(ctx.shape)
+
+
+class _GEGLU(_SwiGLU):
+    FWD, BWD = "amk_geglu_fwd", "amk_geglu_bwd"
 
 
 def swiglu(ab):
     """silu(a) * b for ab = (..., 2H) = (a | b): one HBM pass forward, one backward."""
     return _SwiGLU.apply(ab)
+
+
+def geglu(ab):
+    """gelu(a) * b for ab = (..., 2H) = (a | b) (exact erf GELU): the transformer FFN gate."""
+    return _GEGLU.apply(ab)
 
 
 # ---------------------------------------------------------------------------- residual + LayerNorm

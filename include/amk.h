@@ -263,6 +263,11 @@ int amk_colsum(const float* x, int64_t M, int N, float* part, void* stream);
 int amk_swiglu_fwd(const float* ab, int64_t M, int H, float* out, void* stream);
 int amk_swiglu_bwd(const float* ab, const float* d_out, int64_t M, int H, float* d_ab, void* stream);
 
+/* GEGLU gate of the transformer FFN (models/transformer.py:22-27): out[m, j] = gelu(ab[m, j]) * ab[m, H + j]
+ * with the exact (erf) GELU of F.gelu; same layout and rules as the SwiGLU pair above. */
+int amk_geglu_fwd(const float* ab, int64_t M, int H, float* out, void* stream);
+int amk_geglu_bwd(const float* ab, const float* d_out, int64_t M, int H, float* d_ab, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

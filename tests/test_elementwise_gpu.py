@@ -37,3 +37,26 @@ def test_swiglu_extremes(device):
     a, b = ab.chunk(2, dim=-1)
     assert torch.isfinite(out).all()
     assert_close(out, F.silu(a) * b, 1e-6, "extremes")
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 2 * 96), (1, 1, 8), (2, 300, 2 * 4096), (5, 7, 2 * 20)])
+def test_geglu_matches_reference(device, shape):
+    """amk_geglu_fwd / _bwd against the reference's GEGLU (models/transformer.py:22-27): gate * gelu(val)."""
+    from amk import ops
+
+    ab = seeded(shape, 21 + shape[-1], 2.0)
+    cot = seeded(shape[:-1] + (shape[-1] // 2,), 22 + shape[-1])
+    ref_in = ab.clone().requires_grad_(True)
+    val, gate = ref_in.chunk(2, dim=-1)
+    ref = gate * F.gelu(val)
+    (g_ref,) = torch.autograd.grad((ref * cot).sum(), [ref_in])
+    x = ab.to(device).requires_grad_(True)
+    out = ops.geglu(x)
+    assert tuple(out.shape) == tuple(ref.shape)
+    assert_close(out, ref, 2e-6, "geglu")
+    (g,) = torch.autograd.grad((out * cot.to(device)).sum(), [x])
+    assert_close(g, g_ref, 2e-6, "geglu grad")
+    ext = torch.tensor([[-200.0, -30.0, 0.0, 90.0, 1.0, 2.0, 3.0, 4.0]])
+    o = ops.geglu(ext.to(device)).cpu()
+    assert torch.isfinite(o).all()
+    assert_close(o, ext[:, 4:] * F.gelu(ext[:, :4]), 1e-6, "geglu extremes")
