@@ -19,10 +19,16 @@ class LayerNorm(nn.Module):
         self.gamma = nn.Parameter(torch.ones(dim))
         self.register_buffer("beta", torch.zeros(dim))
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """LN(x), or with ``residual``: (x + residual, LN(x + residual)) from one kernel."""
+        if residual is None:
+            if x.is_cuda:
+                return ops.layer_norm(x, self.gamma, self.beta)   # amk_add_layernorm_fwd / _bwd
+            return F.layer_norm(x, x.shape[-1:], self.gamma, self.beta)
         if x.is_cuda:
-            return ops.layer_norm(x, self.gamma, self.beta)   # amk_add_layernorm_fwd / _bwd
-        return F.layer_norm(x, x.shape[-1:], self.gamma, self.beta)
+            return ops.add_layer_norm(x, residual, self.gamma, self.beta)
+        h = x + residual
+        return h, F.layer_norm(h, h.shape[-1:], self.gamma, self.beta)
 
 
 class GEGLU(nn.Module):
@@ -56,8 +62,9 @@ class EncoderLayer(nn.Module):
         self.norm2 = LayerNorm(dim)
 
     def forward(self, x, context_mask=None):
-        x = self.self_attn(x=self.norm1(x), context_mask=context_mask) + x
-        return self.feed_forward(self.norm2(x)) + x
+        # x + attn(LN(x)), then x + ffn(LN(x)): the first add happens inside the second LayerNorm kernel
+        x, y = self.norm2(x, self.self_attn(x=self.norm1(x), context_mask=context_mask))
+        return self.feed_forward(y) + x
 
 
 class Encoder(nn.Module):
@@ -84,9 +91,10 @@ class DecoderLayer(nn.Module):
         self.norm3 = LayerNorm(dim)
 
     def forward(self, dec_inp, context, context_mask=None, causal_mask=None):
-        x = self.self_attn(x=self.norm1(dec_inp), causal_mask=causal_mask) + dec_inp
-        x = self.cross_attn(x=self.norm2(x), context=context, context_mask=context_mask) + x
-        return self.feed_forward(self.norm3(x)) + x
+        # the adds after self- and cross-attention happen inside the LayerNorm kernels that follow them
+        x, y = self.norm2(dec_inp, self.self_attn(x=self.norm1(dec_inp), causal_mask=causal_mask))
+        x, y = self.norm3(x, self.cross_attn(x=y, context=context, context_mask=context_mask))
+        return self.feed_forward(y) + x
 
 
 class Decoder(nn.Module):
