@@ -14,6 +14,8 @@
 //        16x16 output blocks over ALL 128 keys, so no cross-wave reduction; the result is added
 //        to dq with global_atomic_add_f32 (dq is zeroed by the launcher).  Atomic volume is
 //        8 KiB per (32 query x 128 key) tile = one byte per 320 FLOP.
+// Two workgroup barriers per query tile (the next q / dO tile is committed under the dQ product);
+// workgroups start at rotated query tiles so that co-resident ones are not in the same phase.
 // Results differ from run to run in the last bits of dq only (f32 atomic arrival order); dk, dv are
 // reproducible.  The two-kernel path stays available (AMK_ATTN_BWD_DKDV | AMK_ATTN_BWD_DQ).
 #include "attn_common.h"
