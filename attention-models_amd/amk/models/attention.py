@@ -94,17 +94,27 @@ class SwitchHeadAttention(StackedExpertsMixin, nn.Module):
             # for J != I; no caller uses it (models/vit_moe.py:34 is self).
             raise NotImplementedError("SwitchHeadAttention with a context of another length is a reference quirk, not supported")
         h, d, E, k = self.num_heads, self.dim_head, self.num_experts, self.sel_experts
-        q = self._drop(self.q(x)).view(B, I, h, d).permute(0, 2, 1, 3)
-        kk = self._drop(self.k(src)).view(B, J, h, d).permute(0, 2, 1, 3)
+        if context is None and not (self.dropout_p > 0.0 and self.training):
+            # self-attention: q, k and both gate projections read the same rows -> one GEMM over the
+            # stacked weights (four launches and four passes over x otherwise).  W_d only selects
+            # experts (top-k indices), so it stays without a gradient, as in the reference.
+            W = torch.cat([self.q[0].weight, self.k[0].weight, self.W_s[0].weight, self.W_d[0].weight.detach()], 0)
+            q2, k2, gate_s, gate_d = F.linear(x, W).split([h * d, h * d, h * E, h * E], dim=-1)
+            q = q2.view(B, I, h, d).permute(0, 2, 1, 3)       # strided views of the GEMM output, no copies
+            kk = k2.view(B, J, h, d).permute(0, 2, 1, 3)
+        else:
+            q = self._drop(self.q(x)).view(B, I, h, d).permute(0, 2, 1, 3)
+            kk = self._drop(self.k(src)).view(B, J, h, d).permute(0, 2, 1, 3)
+            gate_s, gate_d = self.W_s(src), self.W_d(src)
         src2 = src.reshape(B * J, self.dim)
         # moe_v: unit = (b, t, head); every unit reads the token's full input row
-        v, sel_v = ops.routed_linear(src2, self.W_s(src).reshape(B * J * h, E), self.experts_v_weight, None,
+        v, sel_v = ops.routed_linear(src2, gate_s.reshape(B * J * h, E), self.experts_v_weight, None,
                                      k, x_div=h * k, weighted=True, outer=1)
         v = v.view(B, J, h, d).permute(0, 2, 1, 3)
         o = ops.attention(q, kk, v, self.scale, key_mask=context_mask, causal_mask=causal_mask)  # (B,h,I,d)
         o2 = o.permute(0, 2, 1, 3).reshape(B * I * h, d)  # 'b i h d' rows, contiguous by construction
         # moe_out: routed by W_d(gate_inputs = src), experts summed un-weighted, then summed over heads
-        out, sel_o = ops.routed_linear(o2, self.W_d(src).reshape(B * J * h, E), self.experts_out_weight, None,
+        out, sel_o = ops.routed_linear(o2, gate_d.reshape(B * J * h, E), self.experts_out_weight, None,
                                        k, x_div=k, weighted=False, outer=h)
         self.last_selected_v = sel_v.view(B, J, h, k)
         self.last_selected_out = sel_o.view(B, J, h, k)
