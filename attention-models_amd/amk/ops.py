@@ -106,6 +106,12 @@ def _mask_u8(mask, shape, what):
     return m.to(torch.uint8).contiguous()
 
 
+# Forward path of the attention core: "f32" = exact-f32 MFMA (v_mfma_f32_32x32x2_f32); "bf16x6" = the same
+# kernel with every product formed from three-way bf16 splits of its f32 operands (six exact partial
+# products, f32 accumulation): f32-level error, 2.6x the matrix rate.  See csrc/attn_fwd_x6.hip.
+ATTENTION_FORWARD = "f32"
+
+
 def _attn_forward(q, k, v, key_mask, causal_mask, scale):
     B, H, I, D = q.shape
     J = k.shape[2]
@@ -116,8 +122,9 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale):
     o = _new_bthd(B, H, I, D, q)
     stats = torch.empty((B, H, I, 2), device=q.device, dtype=torch.float32)
     L = _lib.load()
+    entry = L.amk_attn_fwd_x6 if ATTENTION_FORWARD == "bf16x6" else L.amk_attn_fwd
     with _timed("attn_fwd_kernel"):
-        rc = L.amk_attn_fwd(
+        rc = entry(
             _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(key_mask), _ptr(causal_mask),
             B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
             float(scale), _stream(),

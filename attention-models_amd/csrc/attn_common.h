@@ -102,6 +102,9 @@ __device__ __forceinline__ float f4(const float4& v, int e) {
   return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w));
 }
 
+// attn_fwd_x6.hip: the forward with split-bf16 products
+void launch_attn_fwd_x6(const FwdParams& p, int64_t nwg, hipStream_t st);
+
 // attn_bwd_fused.hip: one-pass backward (dQ by atomics); false = not applicable, nothing launched.
 bool launch_attn_bwd_fused(const BwdParams& p, hipStream_t st);
 

@@ -253,14 +253,14 @@ using namespace amk_attn;
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool strides_ok(const Strides& s) { return (s.sb % 4 == 0) && (s.st % 4 == 0) && (s.sh % 4 == 0); }
 
-extern "C" int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float* stats,
-                            const uint8_t* key_mask, const uint8_t* causal_mask,
-                            int B, int H, int I, int J, int Dh,
-                            int64_t q_sb, int64_t q_st, int64_t q_sh,
-                            int64_t k_sb, int64_t k_st, int64_t k_sh,
-                            int64_t v_sb, int64_t v_st, int64_t v_sh,
-                            int64_t o_sb, int64_t o_st, int64_t o_sh,
-                            float scale, void* stream) {
+static int attn_fwd_impl(bool x6, const float* q, const float* k, const float* v, float* o, float* stats,
+                         const uint8_t* key_mask, const uint8_t* causal_mask,
+                         int B, int H, int I, int J, int Dh,
+                         int64_t q_sb, int64_t q_st, int64_t q_sh,
+                         int64_t k_sb, int64_t k_st, int64_t k_sh,
+                         int64_t v_sb, int64_t v_st, int64_t v_sh,
+                         int64_t o_sb, int64_t o_st, int64_t o_sh,
+                         float scale, void* stream) {
   AMK_CHECK_ARG(q && k && v && o && stats, "amk_attn_fwd: null tensor pointer");
   AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_fwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
   AMK_CHECK_SUPPORTED(Dh == D, "amk_attn_fwd: head dim %d not supported (built for %d)", Dh, D);
@@ -280,10 +280,36 @@ extern "C" int amk_attn_fwd(const float* q, const float* k, const float* v, floa
   AMK_CHECK_SUPPORTED(((int64_t)J + TILE) * k_st * 4 < (1ll << 31) && ((int64_t)J + TILE) * v_st * 4 < (1ll << 31),
                       "amk_attn_fwd: one (batch, head) K/V slab must span < 2 GiB");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (causal_mask)
+  if (x6)
+    launch_attn_fwd_x6(p, nwg, st);
+  else if (causal_mask)
     hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   else
     hipLaunchKernelGGL((attn_fwd_kernel<false, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   AMK_CHECK_LAUNCH("amk_attn_fwd");
   return AMK_OK;
+}
+
+extern "C" int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float* stats,
+                            const uint8_t* key_mask, const uint8_t* causal_mask,
+                            int B, int H, int I, int J, int Dh,
+                            int64_t q_sb, int64_t q_st, int64_t q_sh,
+                            int64_t k_sb, int64_t k_st, int64_t k_sh,
+                            int64_t v_sb, int64_t v_st, int64_t v_sh,
+                            int64_t o_sb, int64_t o_st, int64_t o_sh,
+                            float scale, void* stream) {
+  return attn_fwd_impl(false, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
+                       v_sb, v_st, v_sh, o_sb, o_st, o_sh, scale, stream);
+}
+
+extern "C" int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, float* stats,
+                               const uint8_t* key_mask, const uint8_t* causal_mask,
+                               int B, int H, int I, int J, int Dh,
+                               int64_t q_sb, int64_t q_st, int64_t q_sh,
+                               int64_t k_sb, int64_t k_st, int64_t k_sh,
+                               int64_t v_sb, int64_t v_st, int64_t v_sh,
+                               int64_t o_sb, int64_t o_st, int64_t o_sh,
+                               float scale, void* stream) {
+  return attn_fwd_impl(true, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
+                       v_sb, v_st, v_sh, o_sb, o_st, o_sh, scale, stream);
 }

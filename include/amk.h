@@ -73,6 +73,20 @@ int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float
                  int64_t o_sb, int64_t o_st, int64_t o_sh,
                  float scale, void* stream);
 
+/* The same forward with split-bf16 products: every f32 operand is split into three bf16 parts
+ * (24 mantissa bits) and each product is the sum of six exact partial products accumulated in f32
+ * (v_mfma_f32_32x32x16_bf16).  Same arguments, outputs, statistics and masks; the error against a
+ * double-precision result is that of the f32 MFMA path (1.5e-6 vs 2.6e-6 on K = 64 dot products,
+ * tools/ubench_bf16x6.hip), not that of a bf16 computation.  The backward is amk_attn_bwd either way. */
+int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, float* stats,
+                    const uint8_t* key_mask, const uint8_t* causal_mask,
+                    int B, int H, int I, int J, int D,
+                    int64_t q_sb, int64_t q_st, int64_t q_sh,
+                    int64_t k_sb, int64_t k_st, int64_t k_sh,
+                    int64_t v_sb, int64_t v_st, int64_t v_sh,
+                    int64_t o_sb, int64_t o_st, int64_t o_sh,
+                    float scale, void* stream);
+
 /* Backward of amk_attn_fwd (autograd of the same reference lines).
  * Inputs: q,k,v,o,stats as in the forward, d_o (gradient of o, same addressing
  * as o with its own strides).  Outputs: dq (q-like), dk (k-like), dv (v-like),

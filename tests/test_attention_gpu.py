@@ -14,15 +14,17 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-@pytest.fixture(params=["fused", "deterministic"], autouse=True)
+@pytest.fixture(params=["fused", "deterministic", "fused-x6fwd"], autouse=True)
 def backward_path(request):
-    """Every test runs with both backward paths of the attention core (amk_attn_bwd `stages`)."""
+    """Every test runs with both backward paths of the attention core (amk_attn_bwd `stages`) and
+    with the split-bf16 forward (amk_attn_fwd_x6) in front of the fused backward."""
     from amk import ops
 
-    old = ops.DETERMINISTIC_ATTENTION_BACKWARD
+    old = ops.DETERMINISTIC_ATTENTION_BACKWARD, ops.ATTENTION_FORWARD
     ops.DETERMINISTIC_ATTENTION_BACKWARD = request.param == "deterministic"
+    ops.ATTENTION_FORWARD = "bf16x6" if request.param.endswith("x6fwd") else "f32"
     yield request.param
-    ops.DETERMINISTIC_ATTENTION_BACKWARD = old
+    ops.DETERMINISTIC_ATTENTION_BACKWARD, ops.ATTENTION_FORWARD = old
 
 
 def _core_case(device, B, H, I, J, key_mask=None, causal=None, seed=0, layout="bthd"):
