@@ -26,7 +26,8 @@ SIGNATURES = {
     "amk_arch": (_c.c_char_p, []),
     "amk_last_error": (_c.c_char_p, []),
     "amk_attn_fwd": (_I, [_P] * 7 + [_I] * 5 + [_L] * 12 + [_F, _P]),
-    "amk_attn_fwd_x6": (_I, [_P] * 7 + [_I] * 5 + [_L] * 12 + [_F, _P]),
+    "amk_attn_fwd_x6_ws_bytes": (_L, [_I, _I, _I]),
+    "amk_attn_fwd_x6": (_I, [_P] * 8 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_attn_bwd": (_I, [_P] * 12 + [_I] * 5 + [_L] * 24 + [_F, _I, _P]),
     "amk_vq_num_partials": (_L, [_L]),
     "amk_vq_lookup_fwd": (_I, [_P, _P, _L, _I, _I, _I] + [_P] * 9 + [_P]),

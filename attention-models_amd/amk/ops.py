@@ -5,6 +5,7 @@ the hot path runs in the HIP kernels of ``csrc/``.  Inputs must be fp32 HIP tens
 is deliberately no CPU / eager path ("no fallback").
 """
 import ctypes
+import os
 
 import torch
 
@@ -109,7 +110,7 @@ def _mask_u8(mask, shape, what):
 # Forward path of the attention core: "f32" = exact-f32 MFMA (v_mfma_f32_32x32x2_f32); "bf16x6" = the same
 # kernel with every product formed from three-way bf16 splits of its f32 operands (six exact partial
 # products, f32 accumulation): f32-level error, 2.6x the matrix rate.  See csrc/attn_fwd_x6.hip.
-ATTENTION_FORWARD = "f32"
+ATTENTION_FORWARD = os.environ.get("AMK_ATTENTION_FORWARD", "f32")
 
 
 def _attn_forward(q, k, v, key_mask, causal_mask, scale):
@@ -122,13 +123,21 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale):
     o = _new_bthd(B, H, I, D, q)
     stats = torch.empty((B, H, I, 2), device=q.device, dtype=torch.float32)
     L = _lib.load()
-    entry = L.amk_attn_fwd_x6 if ATTENTION_FORWARD == "bf16x6" else L.amk_attn_fwd
+    x6 = ATTENTION_FORWARD == "bf16x6"
+    ws = torch.empty((L.amk_attn_fwd_x6_ws_bytes(B, H, J),), device=q.device, dtype=torch.uint8) if x6 else None
     with _timed("attn_fwd_kernel"):
-        rc = entry(
-            _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(key_mask), _ptr(causal_mask),
-            B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
-            float(scale), _stream(),
-        )
+        if x6:
+            rc = L.amk_attn_fwd_x6(
+                _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(ws), _ptr(key_mask), _ptr(causal_mask),
+                B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
+                float(scale), _stream(),
+            )
+        else:
+            rc = L.amk_attn_fwd(
+                _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(key_mask), _ptr(causal_mask),
+                B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
+                float(scale), _stream(),
+            )
     _lib.check(rc, "amk_attn_fwd")
     return q, k, v, o, stats
 

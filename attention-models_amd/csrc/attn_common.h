@@ -31,6 +31,7 @@ struct FwdParams {
   float scale;
   float pinf;  // +infinity, passed at run time (see vmax)
   int nblk;  // ceil(I / BLK)
+  void* x6_ws;  // split-bf16 forward: K / V planes, B*H*ceil(J/64) tiles of 48 KiB (attn_fwd_x6.hip)
 };
 
 struct BwdParams {

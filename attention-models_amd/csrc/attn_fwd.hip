@@ -253,7 +253,7 @@ using namespace amk_attn;
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool strides_ok(const Strides& s) { return (s.sb % 4 == 0) && (s.st % 4 == 0) && (s.sh % 4 == 0); }
 
-static int attn_fwd_impl(bool x6, const float* q, const float* k, const float* v, float* o, float* stats,
+static int attn_fwd_impl(void* x6_ws, bool x6, const float* q, const float* k, const float* v, float* o, float* stats,
                          const uint8_t* key_mask, const uint8_t* causal_mask,
                          int B, int H, int I, int J, int Dh,
                          int64_t q_sb, int64_t q_st, int64_t q_sh,
@@ -272,6 +272,8 @@ static int attn_fwd_impl(bool x6, const float* q, const float* k, const float* v
   p.scale = scale;
   p.pinf = INFINITY;
   p.nblk = (I + BLK - 1) / BLK;
+  p.x6_ws = x6_ws;
+  AMK_CHECK_ARG(!x6 || (x6_ws && aligned16(x6_ws)), "amk_attn_fwd_x6: workspace missing or not 16-byte aligned");
   AMK_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && strides_ok(p.qs) &&
                     strides_ok(p.ks) && strides_ok(p.vs) && strides_ok(p.os),
                 "amk_attn_fwd: pointers must be 16-byte aligned and strides multiples of 4 elements");
@@ -298,11 +300,16 @@ extern "C" int amk_attn_fwd(const float* q, const float* k, const float* v, floa
                             int64_t v_sb, int64_t v_st, int64_t v_sh,
                             int64_t o_sb, int64_t o_st, int64_t o_sh,
                             float scale, void* stream) {
-  return attn_fwd_impl(false, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
+  return attn_fwd_impl(nullptr, false, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
                        v_sb, v_st, v_sh, o_sb, o_st, o_sh, scale, stream);
 }
 
-extern "C" int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, float* stats,
+extern "C" int64_t amk_attn_fwd_x6_ws_bytes(int B, int H, int J) {
+  if (B <= 0 || H <= 0 || J <= 0) return 0;
+  return (int64_t)B * H * ((J + TILE - 1) / TILE) * 2 * 24576;
+}
+
+extern "C" int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, float* stats, void* ws,
                                const uint8_t* key_mask, const uint8_t* causal_mask,
                                int B, int H, int I, int J, int Dh,
                                int64_t q_sb, int64_t q_st, int64_t q_sh,
@@ -310,6 +317,6 @@ extern "C" int amk_attn_fwd_x6(const float* q, const float* k, const float* v, f
                                int64_t v_sb, int64_t v_st, int64_t v_sh,
                                int64_t o_sb, int64_t o_st, int64_t o_sh,
                                float scale, void* stream) {
-  return attn_fwd_impl(true, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
+  return attn_fwd_impl(ws, true, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
                        v_sb, v_st, v_sh, o_sb, o_st, o_sh, scale, stream);
 }

@@ -8,10 +8,12 @@
 // (tools/ubench_bf16x6.hip): the error of a K = 64 dot product against double precision is
 // 1.5e-6, the exact-f32 v_mfma_f32_32x32x2_f32 gives 2.6e-6 -- it is not a reduced-precision
 // path -- and six of these MFMAs do a 32x32x16 block in 192 matrix cycles where the f32 MFMA
-// needs 512 (399 against 155 algorithmic TFLOP/s).  The price is VALU work to split what is not
-// split yet: K / V elements once per tile while they are staged into LDS (as three bf16 planes;
-// V transposed, so that its A-operand fragments are single 16-byte reads), P once per tile
-// out of the S accumulators.
+// needs 512 (399 against 155 algorithmic TFLOP/s).  The price is VALU work to split the operands
+// (about 5.5 instructions per element, and the bf16 MFMA hides only about two VALU instructions
+// per MFMA): so K and V are split ONCE per call by a pre-pass (attn_split_kv_kernel, three bf16
+// planes per tile; V transposed and in accumulator key order, so that its A-operand fragments are
+// single 16-byte reads) instead of once per query block, Q once per wave, and only P -- which
+// exists nowhere else -- inside the tile loop, out of the S accumulators.
 //
 //   S^T (keys x queries) = K Q^T : A = K rows (LDS, 8 consecutive d per lane), B = Q^T (registers)
 //   O^T (dims x queries) += V^T P^T : A = V^T rows (LDS, 8 keys per lane in accumulator order),
@@ -41,6 +43,15 @@ __device__ __forceinline__ f32x16 mfma6(const bf16x8 (&a)[3], const bf16x8 (&b)[
   c = mfmab(a[0], b[1], c);
   c = mfmab(a[0], b[0], c);
   return c;
+}
+// two independent accumulators fed by the same B planes, MFMAs alternating so that no MFMA waits on its predecessor
+__device__ __forceinline__ void mfma6x2(const bf16x8 (&a0)[3], const bf16x8 (&a1)[3], const bf16x8 (&b)[3], f32x16& c0, f32x16& c1) {
+  c0 = mfmab(a0[1], b[1], c0); c1 = mfmab(a1[1], b[1], c1);
+  c0 = mfmab(a0[2], b[0], c0); c1 = mfmab(a1[2], b[0], c1);
+  c0 = mfmab(a0[0], b[2], c0); c1 = mfmab(a1[0], b[2], c1);
+  c0 = mfmab(a0[1], b[0], c0); c1 = mfmab(a1[1], b[0], c1);
+  c0 = mfmab(a0[0], b[1], c0); c1 = mfmab(a1[0], b[1], c1);
+  c0 = mfmab(a0[0], b[0], c0); c1 = mfmab(a1[0], b[0], c1);
 }
 __device__ __forceinline__ void split1(float x, __bf16& h, __bf16& m, __bf16& l) {
   h = (__bf16)x;
@@ -100,55 +111,44 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_x6_kernel(FwdParams p) {
     }
   }
 
-  const float* kbase = p.k + (int64_t)b * p.ks.sb + (int64_t)h * p.ks.sh;
-  const float* vbase = p.v + (int64_t)b * p.vs.sb + (int64_t)h * p.vs.sh;
   const uint8_t* kmask = p.key_mask ? p.key_mask + (int64_t)b * p.J : nullptr;
   const uint8_t* cmrow = CAUSAL ? p.causal_mask + (int64_t)qi * p.J : nullptr;
 
-  // staging.  K: thread -> (row = tid/16 + 16*pass, 4 floats at column 4*(tid%16)) as in attn_fwd.hip.
-  // V: thread -> (key quad kq = tid/16: rows 4*kq + i, 4 floats at column 4*(tid%16)): a 4 keys x 4 dims
-  // block, so that after the split every (plane, dim) owns 4 consecutive key positions = one 8-byte write.
-  const int srow = tid >> 4, scol = (tid & 15) * 4;
-  float4 kst[4], vst[4];
-  float fillst = 0.f;
-  RowStager kload, vload;
-  kload.init(kbase, p.ks.st, p.J, tid);
-  vload.init(vbase, p.vs.st, p.J, tid);
+  // staging: the pre-pass left, per (batch, head, 64-key tile), 24 KB of K planes [key][plane][64 d] and
+  // 24 KB of V^T planes [dim][plane][64 key positions], contiguous: 1536 16-byte chunks each, six per thread.
+  const int ntile = (p.J + TILE - 1) / TILE;
+  // one buffer descriptor over this (batch, head)'s tiles; chunk c of tile t is at byte (t*3072 + c)*16
+  const __amdgpu_buffer_rsrc_t wsrc = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<char*>(p.x6_ws) + (int64_t)bh * ntile * 2 * 24576, 0, ntile * 2 * 24576, 0x00020000);
+  float4 kch[6], vch[6];
+  int lds_off[6];   // bf16 index inside a 3-plane LDS tile for chunk tid + 256*n
 #pragma unroll
-  for (int i = 0; i < 4; ++i) vload.voff[i] = (int)(((int64_t)(4 * srow + i) * p.vs.st + scol) * 4);
-  // position of key quad kq inside its 16-key group: accumulator order [0..3, 8..11, 4..7, 12..15]
-  const int vpos = 16 * (srow >> 2) + 4 * (((srow & 1) << 1) | ((srow >> 1) & 1));
-  auto prefetch = [&](int j0) {
-    kload.load(kst);
-    vload.load(vst);
+  for (int n = 0; n < 6; ++n) {
+    const int c = tid + 256 * n;
+    const int row = c / 24, plane = (c % 24) >> 3, k8 = c & 7;
+    lds_off[n] = plane * PLANE + row * PSTR + 8 * k8;
+  }
+  float fillst = 0.f;
+  auto prefetch = [&](int t) {
+    const int base = t * 2 * 24576 + tid * 16;
+#pragma unroll
+    for (int n = 0; n < 6; ++n) {
+      kch[n] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, base + 4096 * n, 0, 0));
+      vch[n] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(wsrc, base + 24576 + 4096 * n, 0, 0));
+    }
     if (tid < TILE) {
-      const int j = j0 + tid;
+      const int j = t * TILE + tid;
       float f = 0.f;
       if (j >= p.J) f = -INFINITY;                       // beyond the sequence: weight 0
       else if (kmask && kmask[j] == 0) f = AMK_FILL_MASKED;  // masked_fill(~context_mask, -1e9)
       fillst = f;
     }
   };
-  // split(): f32 staging registers of the next tile -> bf16 planes, VALU only (placed among the MFMAs of the
-  // current tile); commit(): the planes -> LDS, between the two barriers
-  bf16x4 kpl[4][3], vpl[4][3];
-  auto split = [&]() {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) split4(kst[ps].x, kst[ps].y, kst[ps].z, kst[ps].w, kpl[ps]);
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd) split4(f4(vst[0], dd), f4(vst[1], dd), f4(vst[2], dd), f4(vst[3], dd), vpl[dd]);
-  };
   auto commit = [&]() {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int r = srow + 16 * ps;
-#pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(&Kp[q * PLANE + r * PSTR + scol]) = kpl[ps][q];
-    }
-#pragma unroll
-    for (int dd = 0; dd < 4; ++dd) {   // dim scol + dd of keys 4*srow .. 4*srow + 3
-#pragma unroll
-      for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(&Vt[q * PLANE + (scol + dd) * PSTR + vpos]) = vpl[dd][q];
+    for (int n = 0; n < 6; ++n) {
+      *reinterpret_cast<float4*>(&Kp[lds_off[n]]) = kch[n];
+      *reinterpret_cast<float4*>(&Vt[lds_off[n]]) = vch[n];
     }
     if (tid < TILE) Kfill[tid] = fillst;
   };
@@ -156,15 +156,13 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_x6_kernel(FwdParams p) {
   f32x16 o0 = zero16(), o1 = zero16();
   float m_run = -INFINITY, l_run = 0.f;
 
-  const int ntile = (p.J + TILE - 1) / TILE;
   prefetch(0);
-  split();
   for (int t = 0; t < ntile; ++t) {
     const int j0 = t * TILE;
     __syncthreads();  // every wave is done reading the previous tile
     commit();
     __syncthreads();
-    if (t + 1 < ntile) prefetch(j0 + TILE);
+    if (t + 1 < ntile) prefetch(t + 1);
 
     unsigned cbits0 = 0, cbits1 = 0;
     if (CAUSAL) {
@@ -188,8 +186,7 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_x6_kernel(FwdParams p) {
         ka[q] = *reinterpret_cast<const bf16x8*>(&Kp[q * PLANE + ln * PSTR + 16 * c + 8 * hf]);
         kb2[q] = *reinterpret_cast<const bf16x8*>(&Kp[q * PLANE + (32 + ln) * PSTR + 16 * c + 8 * hf]);
       }
-      s0 = mfma6(ka, qpl[c], s0);
-      s1 = mfma6(kb2, qpl[c], s1);
+      mfma6x2(ka, kb2, qpl[c], s0, s1);
     }
 
     // ---- fills and online softmax: as attn_fwd.hip ----
@@ -246,8 +243,6 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_x6_kernel(FwdParams p) {
     }
     l_run += lsum;
 
-    if (t + 1 < ntile) split();   // the next tile's K / V: VALU work the scheduler can put among the MFMAs below
-
     // ---- O^T += V^T P^T: 4 groups of 16 keys x 2 dim blocks x 6 MFMAs ----
     // group g = 2*blk + t: registers 8t..8t+7 of S^T block blk are keys 32*blk + 16*t + 4*half + (j&3) + 8*(j>>2)
 #pragma unroll
@@ -263,8 +258,7 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_x6_kernel(FwdParams p) {
         va[q] = *reinterpret_cast<const bf16x8*>(&Vt[q * PLANE + ln * PSTR + 16 * g + 8 * hf]);
         vb[q] = *reinterpret_cast<const bf16x8*>(&Vt[q * PLANE + (32 + ln) * PSTR + 16 * g + 8 * hf]);
       }
-      o0 = mfma6(va, pp, o0);
-      o1 = mfma6(vb, pp, o1);
+      mfma6x2(va, vb, pp, o0, o1);
     }
   }
 
@@ -286,7 +280,54 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_x6_kernel(FwdParams p) {
   }
 }
 
+// Pre-pass: one workgroup per (batch, head, 64-key tile) splits the K and V rows of the tile into bf16 planes.
+//   K tile  -> [key 0..63][plane 0..2][64 d]
+//   V tile  -> [dim 0..63][plane 0..2][64 key positions]; inside each group of 16 keys the positions are in
+//              accumulator order [0..3, 8..11, 4..7, 12..15] (the k-slots of a P^T fragment)
+// Rows beyond the sequence are written as zeros.
+__global__ __launch_bounds__(WG) void attn_split_kv_kernel(FwdParams p) {
+  const int tid = threadIdx.x;
+  const int ntile = (p.J + TILE - 1) / TILE;
+  const int t = blockIdx.x % ntile;
+  const int bh = blockIdx.x / ntile;
+  const int h = bh % p.H, b = bh / p.H;
+  const float* kbase = p.k + (int64_t)b * p.ks.sb + (int64_t)h * p.ks.sh;
+  const float* vbase = p.v + (int64_t)b * p.vs.sb + (int64_t)h * p.vs.sh;
+  __bf16* out = reinterpret_cast<__bf16*>(p.x6_ws) + ((int64_t)bh * ntile + t) * 2 * 1536 * 8;
+  const int srow = tid >> 4, scol = (tid & 15) * 4;
+  RowStager kload, vload;
+  kload.init(kbase, p.ks.st, p.J, tid);
+  vload.init(vbase, p.vs.st, p.J, tid);
+  kload.seek(t, p.ks.st, tid);
+  vload.seek(t, p.vs.st, tid);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) vload.voff[i] = (int)(((int64_t)(4 * srow + i) * p.vs.st + scol) * 4) + t * vload.step;
+  float4 kst[4], vst[4];
+  kload.load(kst);
+  vload.load(vst);
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {   // K: row srow + 16*ps, dims scol..scol+3
+    bf16x4 pl[3];
+    split4(kst[ps].x, kst[ps].y, kst[ps].z, kst[ps].w, pl);
+    const int r = srow + 16 * ps;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(out + (r * 3 + q) * 64 + scol) = pl[q];
+  }
+  // V: this thread holds keys 4*srow .. 4*srow+3 x dims scol..scol+3; position of the key quad in its 16-group
+  const int vpos = 16 * (srow >> 2) + 4 * (((srow & 1) << 1) | ((srow >> 1) & 1));
+  __bf16* vout = out + 1536 * 8;
+#pragma unroll
+  for (int dd = 0; dd < 4; ++dd) {
+    bf16x4 pl[3];
+    split4(f4(vst[0], dd), f4(vst[1], dd), f4(vst[2], dd), f4(vst[3], dd), pl);
+#pragma unroll
+    for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x4*>(vout + ((scol + dd) * 3 + q) * 64 + vpos) = pl[q];
+  }
+}
+
 void launch_attn_fwd_x6(const FwdParams& p, int64_t nwg, hipStream_t st) {
+  const int ntile = (p.J + TILE - 1) / TILE;
+  hipLaunchKernelGGL(attn_split_kv_kernel, dim3((unsigned)((int64_t)p.B * p.H * ntile)), dim3(WG), 0, st, p);
   if (p.causal_mask)
     hipLaunchKernelGGL(attn_fwd_x6_kernel<true>, dim3((unsigned)nwg), dim3(WG), 0, st, p);
   else

@@ -92,6 +92,12 @@ def kernel_rooflines(B, dev, iters):
     t = time_launches(lambda: ops._attn_forward(q, k, v, None, None, scale), iters)
     out.append(dict(kernel="attn_fwd_kernel", launches_per_step=layers_f, avg_ms=t * 1e3, flop=core,
                     note="4*B*h*I*J*d"))
+    old_mode, ops.ATTENTION_FORWARD = ops.ATTENTION_FORWARD, "bf16x6"
+    t = time_launches(lambda: ops._attn_forward(q, k, v, None, None, scale), iters)
+    ops.ATTENTION_FORWARD = old_mode
+    out.append(dict(kernel="attn_fwd_x6 (split pre-pass + kernel)", launches_per_step=0, avg_ms=t * 1e3, flop=core,
+                    note="the forward with split-bf16 products (amk_attn_fwd_x6); its bound is the bf16 MFMA peak / 6, "
+                         "not the f32 MFMA peak the fraction below is taken against"))
     t = time_launches(lambda: bwd(8), iters)
     out.append(dict(kernel="attn_bwd_fused_kernel", launches_per_step=layers_b, avg_ms=t * 1e3, flop=2 * core,
                     note="8*B*h*I*J*d (dV,dP,dQ,dK; recomputed S not credited); includes the dq memset"))
@@ -201,6 +207,25 @@ def main():
                   "what": "generator forward run once per step and shared by the discriminator and generator "
                           "phases (the reference runs it twice on unchanged weights); not the headline value"}
         note("shared-forward variant done")
+    # informational variant (never `value`): the reference-shaped step with the attention FORWARD on split-bf16
+    # products (amk_attn_fwd_x6: f32 operands, six exact bf16 partial products per product, f32 accumulation;
+    # measured error below the f32 MFMA path's).  The headline keeps the exact-f32 MFMA forward.
+    x6 = None
+    if world == 1 and not args.no_variants:
+        prev_mode, amk_ops.ATTENTION_FORWARD = amk_ops.ATTENTION_FORWARD, "bf16x6"
+        for _ in range(2):
+            trainer.step(imgs)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.step(imgs)
+        sync()
+        dx = time.perf_counter() - t1
+        amk_ops.ATTENTION_FORWARD = prev_mode
+        x6 = {"value": args.batch * args.steps / dx, "unit": "images/s", "ms_per_step": dx / args.steps * 1e3,
+              "what": "attention forward with split-bf16 (bf16x6) products, f32-level error; backward and everything "
+                      "else as in the headline; not the headline value"}
+        note("split-bf16 forward variant done")
 
     kernels = None
     if rank == 0 and not args.no_kernels:
@@ -281,6 +306,8 @@ def main():
             }
         if shared:
             line["variant_shared_generator_forward"] = shared
+        if x6:
+            line["variant_split_bf16_attention_forward"] = x6
         if kernels:
             line["kernels_microbench"] = kernels
         if cpu:

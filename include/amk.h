@@ -77,8 +77,11 @@ int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float
  * (24 mantissa bits) and each product is the sum of six exact partial products accumulated in f32
  * (v_mfma_f32_32x32x16_bf16).  Same arguments, outputs, statistics and masks; the error against a
  * double-precision result is that of the f32 MFMA path (1.5e-6 vs 2.6e-6 on K = 64 dot products,
- * tools/ubench_bf16x6.hip), not that of a bf16 computation.  The backward is amk_attn_bwd either way. */
-int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, float* stats,
+ * tools/ubench_bf16x6.hip), not that of a bf16 computation.  The backward is amk_attn_bwd either way.
+ * ws: amk_attn_fwd_x6_ws_bytes(B, H, J) bytes (48 KiB per (batch, head, 64-key tile): K and V split into
+ * bf16 planes once per call by a pre-pass); contents undefined on return. */
+int64_t amk_attn_fwd_x6_ws_bytes(int B, int H, int J);
+int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, float* stats, void* ws,
                     const uint8_t* key_mask, const uint8_t* causal_mask,
                     int B, int H, int I, int J, int D,
                     int64_t q_sb, int64_t q_st, int64_t q_sh,
