@@ -3,19 +3,25 @@ side HIP stream, overlapped with the rest of backward.
 
 This replaces what ``accelerate.Accelerator.prepare(model)`` injects in the reference
 (DistributedDataParallel; trainers/vitgqgan.py:99-109, trainers/utils/base_trainer.py:29-33):
-the forward needs no communication, the only exchange is one SUM all-reduce of the fp32
+the forward needs no communication, the only exchange is one all-reduce of the fp32
 gradients per optimizer step, averaged over ranks.
 
 Design (MI355X: 7 xGMI links x ~153 GB/s per GPU, ring collectives are per-link bound):
   * gradients live in a few large contiguous fp32 buckets (default 32 MiB) laid out in REVERSE
     registration order, so the first bucket to complete in backward is the first one sent;
-    ``param.grad`` is a view into its bucket (no flatten / unflatten copies);
-  * a post-accumulate hook per parameter counts a bucket down; when its last gradient lands,
-    the compute stream records an event, the side stream waits on it and issues the
-    all-reduce there, followed by the 1/world scale -- compute never blocks;
+    ``param.grad`` is a view into its bucket (no flatten / unflatten copies); every parameter
+    starts on a 1-KiB boundary of its bucket, which is what lets amk.optim.FlatAdam walk a bucket
+    in 256-element segments that each belong to one parameter;
+  * a post-accumulate hook per parameter counts a bucket down; when its last gradient lands and
+    every EARLIER bucket has been sent, the compute stream records an event, the side stream waits
+    on it and issues the all-reduce there (RCCL: ``ReduceOp.AVG``, no separate 1/world pass) --
+    compute never blocks.  Buckets always leave in index order, on every rank, whatever the order
+    in which autograd finishes them: the collectives of the ranks pair up by construction;
   * ``finish()`` sends buckets whose parameters produced no gradient this step (the
     reference has such parameters: SwitchHeadAttention.W_d, frozen sub-models -- a stock DDP
-    wrap would raise) and makes the compute stream wait for the side stream;
+    wrap would raise), makes the compute stream wait for the side stream, and detaches ``.grad``
+    of the parameters that received none since the last ``zero_grad()`` -- torch optimizers then
+    skip them as they do in the reference (no weight decay, no moment update);
   * ``begin(sync=False)`` skips communication for gradient-accumulation micro-steps
     (``accelerator.accumulate`` / ``no_sync`` semantics).
 Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 tests).
@@ -23,13 +29,16 @@ Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 t
 import torch
 import torch.distributed as dist
 
+ALIGN = 256  # elements: a parameter's slice of its bucket starts on a 1-KiB boundary
+
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "pending", "launched", "work")
+    __slots__ = ("flat", "params", "views", "offsets", "pending", "ready", "launched", "work", "fired")
 
-    def __init__(self, flat, params, views):
-        self.flat, self.params, self.views = flat, params, views
-        self.pending, self.launched, self.work = len(params), False, None
+    def __init__(self, flat, params, views, offsets):
+        self.flat, self.params, self.views, self.offsets = flat, params, views, offsets
+        self.pending, self.ready, self.launched, self.work = len(params), False, False, None
+        self.fired = [False] * len(params)
 
 
 class GradReducer:
@@ -43,13 +52,17 @@ class GradReducer:
         self.alone = self.world == 1 and not (communicate_when_alone and dist.is_initialized())
         dev = self.params[0].device
         self.on_gpu = dev.type == "cuda"
+        # RCCL averages inside the collective; gloo (CPU tests, shared-GPU rehearsal) has no AVG
+        self.avg_in_collective = (not self.alone) and dist.get_backend(process_group) == "nccl"
         self.side = torch.cuda.Stream(device=dev) if self.on_gpu else None
         self.sync_step = True
         self.buckets = []
         self._bucket_of = {}
+        self._next = 0  # index of the next bucket to send
+        self.launch_order = []  # bucket indices in the order they left this step (tests read it)
         cur, cur_bytes = [], 0
         for p in reversed(self.params):
-            nbytes = p.numel() * 4
+            nbytes = -(-p.numel() // ALIGN) * ALIGN * 4
             if cur and cur_bytes + nbytes > bucket_bytes:
                 self._close(cur, dev)
                 cur, cur_bytes = [], 0
@@ -63,15 +76,17 @@ class GradReducer:
     def _close(self, params, dev):
         if any(p.dtype != torch.float32 for p in params):
             raise TypeError("GradReducer reduces fp32 gradients")
-        total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        views, off = [], 0
+        offsets, off = [], 0
         for p in params:
-            v = flat[off:off + p.numel()].view_as(p)
+            offsets.append(off)
+            off += -(-p.numel() // ALIGN) * ALIGN
+        flat = torch.zeros(off, device=dev, dtype=torch.float32)
+        views = []
+        for p, o in zip(params, offsets):
+            v = flat[o:o + p.numel()].view_as(p)
             p.grad = v
             views.append(v)
-            off += p.numel()
-        b = _Bucket(flat, params, views)
+        b = _Bucket(flat, params, views, offsets)
         for i, p in enumerate(params):
             self._bucket_of[p] = (b, i)
         self.buckets.append(b)
@@ -86,14 +101,27 @@ class GradReducer:
     def begin(self, sync=True):
         """Call before backward.  sync=False: accumulate locally, no communication this step."""
         self.sync_step = sync
+        self._next = 0
+        self.launch_order = []
         for b in self.buckets:
-            b.pending, b.launched, b.work = len(b.params), False, None
+            b.pending, b.ready, b.launched, b.work = len(b.params), False, False, None
+            for p, v in zip(b.params, b.views):
+                if p.grad is None:
+                    p.grad = v  # detached by finish() of an earlier step: accumulate into the bucket again
 
     def zero_grad(self):
         for b in self.buckets:
             b.flat.zero_()
+            b.fired = [False] * len(b.params)
             for p, v in zip(b.params, b.views):
-                p.grad = v  # re-attach if an optimizer set it to None
+                p.grad = v  # re-attach if finish() or an optimizer set it to None
+
+    def mark_zeroed(self):
+        """The buckets were zeroed by someone else (amk.optim.FlatAdam does it inside its update pass)."""
+        for b in self.buckets:
+            b.fired = [False] * len(b.params)
+            for p, v in zip(b.params, b.views):
+                p.grad = v
 
     def _on_grad(self, p):
         b, i = self._bucket_of[p]
@@ -101,12 +129,22 @@ class GradReducer:
         if p.grad.data_ptr() != view.data_ptr():
             view.copy_(p.grad)  # autograd (create_graph) or an optimizer replaced .grad: fold it back
             p.grad = view
+        b.fired[i] = True
         b.pending -= 1
-        if b.pending == 0 and self.sync_step:
-            self._launch(b)
+        if b.pending == 0:
+            b.ready = True
+            if self.sync_step:
+                self._launch_ready()
 
-    def _launch(self, b):
+    def _launch_ready(self):
+        while self._next < len(self.buckets) and self.buckets[self._next].ready:
+            self._launch(self._next)
+            self._next += 1
+
+    def _launch(self, idx):
+        b = self.buckets[idx]
         b.launched = True
+        self.launch_order.append(idx)
         if self.alone:
             return
         if self.on_gpu:
@@ -114,28 +152,39 @@ class GradReducer:
             ready.record(torch.cuda.current_stream())
             self.side.wait_event(ready)
             with torch.cuda.stream(self.side):
-                dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
-                b.flat.mul_(1.0 / self.world)
+                if self.avg_in_collective:
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.AVG, group=self.group)
+                else:
+                    dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group)
+                    b.flat.mul_(1.0 / self.world)
         else:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def finish(self):
+    def finish(self, detach_unused=True):
         """Call after backward, before clip / optimizer.step()."""
         if not self.sync_step:
             return
         for b in self.buckets:
-            if not b.launched:  # parameters without a gradient this step: zeros travel
-                self._launch(b)
-        if self.alone:
-            return
-        if self.on_gpu:
-            torch.cuda.current_stream().wait_stream(self.side)
-        else:
+            b.ready = True  # parameters without a gradient this step: zeros travel
+        self._launch_ready()
+        if not self.alone:
+            if self.on_gpu:
+                torch.cuda.current_stream().wait_stream(self.side)
+            else:
+                for b in self.buckets:
+                    if b.work is not None:
+                        b.work.wait()
+                        b.flat.mul_(1.0 / self.world)
+                        b.work = None
+        if detach_unused:
             for b in self.buckets:
-                if b.work is not None:
-                    b.work.wait()
-                    b.flat.mul_(1.0 / self.world)
-                    b.work = None
+                for p, f in zip(b.params, b.fired):
+                    if not f:
+                        p.grad = None  # the reference leaves .grad None here: optimizers skip the parameter
+
+    def unused_parameters(self):
+        """Parameters that received no gradient since the last zero_grad()."""
+        return [p for b in self.buckets for p, f in zip(b.params, b.fired) if not f]
 
     def grads_nbytes(self):
         return sum(b.flat.numel() for b in self.buckets) * 4

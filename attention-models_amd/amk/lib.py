@@ -26,9 +26,12 @@ SIGNATURES = {
     "amk_arch": (_c.c_char_p, []),
     "amk_last_error": (_c.c_char_p, []),
     "amk_attn_fwd": (_I, [_P] * 7 + [_I] * 5 + [_L] * 12 + [_F, _P]),
+    "amk_attn_scores_bytes": (_L, [_I, _I, _I, _I]),
+    "amk_attn_fwd_keep": (_I, [_P] * 8 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_attn_fwd_x6_ws_bytes": (_L, [_I, _I, _I]),
     "amk_attn_fwd_x6": (_I, [_P] * 8 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_attn_bwd": (_I, [_P] * 12 + [_I] * 5 + [_L] * 24 + [_F, _I, _P]),
+    "amk_attn_bwd_kept": (_I, [_P] * 13 + [_I] * 5 + [_L] * 24 + [_F, _I, _P]),
     "amk_vq_num_partials": (_L, [_L]),
     "amk_vq_lookup_fwd": (_I, [_P, _P, _L, _I, _I, _I] + [_P] * 9 + [_P]),
     "amk_vq_lookup_bwd": (_I, [_P] * 7 + [_F, _L, _I, _I, _P, _P, _P]),
@@ -45,6 +48,9 @@ SIGNATURES = {
     "amk_swiglu_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
     "amk_geglu_fwd": (_I, [_P, _L, _I, _P, _P]),
     "amk_geglu_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
+    "amk_opt_num_partials": (_I, []),
+    "amk_sumsq_partials": (_I, [_P, _L, _P, _P]),
+    "amk_adam_flat_step": (_I, [_P] * 4 + [_L, _P, _P, _P, _I] + [_F] * 6 + [_I, _P, _P]),
     "amk_moe_route_ws_ints": (_L, [_L, _I, _I]),
     "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 8),
     "amk_grouped_gemm_nt": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),

@@ -112,8 +112,19 @@ def _mask_u8(mask, shape, what):
 # products, f32 accumulation): f32-level error, 2.6x the matrix rate.  See csrc/attn_fwd_x6.hip.
 ATTENTION_FORWARD = os.environ.get("AMK_ATTENTION_FORWARD", "f32")
 
+# Training: the forward leaves the raw scores S (4 bytes per (b, h, i, j), 32x32 tiles) in HBM and the fused
+# backward reads them back instead of recomputing S = QK^T -- four matrix products instead of five, bit for
+# bit the same results.  The reference keeps the same tensor alive for autograd; 288 GB of HBM make it
+# affordable here (1.07 GB per ViT-VQGAN layer at batch 32, 12.9 GB for the twelve layers).  A call whose
+# scores would exceed ATTENTION_KEEP_SCORES_MAX_BYTES recomputes instead.
+ATTENTION_KEEP_SCORES = os.environ.get("AMK_ATTN_KEEP_SCORES", "1") == "1"
+ATTENTION_KEEP_SCORES_MAX_BYTES = 8 << 30
+# keys per workgroup of the fused backward: 0 = library default, 128 or 256
+ATTENTION_BACKWARD_KEYS = int(os.environ.get("AMK_ATTN_BWD_KEYS", "0"))
 
-def _attn_forward(q, k, v, key_mask, causal_mask, scale):
+
+def _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=False):
+    """Returns (q, k, v, o, stats, scores); scores is None unless keep_scores and the f32 kernel ran."""
     B, H, I, D = q.shape
     J = k.shape[2]
     _require_device(q, k, v, key_mask, causal_mask)
@@ -125,8 +136,19 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale):
     L = _lib.load()
     x6 = ATTENTION_FORWARD == "bf16x6"
     ws = torch.empty((L.amk_attn_fwd_x6_ws_bytes(B, H, J),), device=q.device, dtype=torch.uint8) if x6 else None
-    with _timed("attn_fwd_kernel"):
-        if x6:
+    scores = None
+    if keep_scores and not x6 and causal_mask is None and ATTENTION_KEEP_SCORES and not DETERMINISTIC_ATTENTION_BACKWARD:
+        nbytes = L.amk_attn_scores_bytes(B, H, I, J)
+        if nbytes <= ATTENTION_KEEP_SCORES_MAX_BYTES:
+            scores = torch.empty((nbytes // 4,), device=q.device, dtype=torch.float32)
+    with _timed("attn_fwd_keep_kernel" if scores is not None else "attn_fwd_kernel"):
+        if scores is not None:
+            rc = L.amk_attn_fwd_keep(
+                _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(scores), _ptr(key_mask), _ptr(causal_mask),
+                B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
+                float(scale), _stream(),
+            )
+        elif x6:
             rc = L.amk_attn_fwd_x6(
                 _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(ws), _ptr(key_mask), _ptr(causal_mask),
                 B, H, I, J, D, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o),
@@ -139,7 +161,7 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale):
                 float(scale), _stream(),
             )
     _lib.check(rc, "amk_attn_fwd")
-    return q, k, v, o, stats
+    return q, k, v, o, stats, scores
 
 
 # Backward path of the attention core: False (default) = one fused pass, each product computed once,
@@ -148,9 +170,14 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale):
 DETERMINISTIC_ATTENTION_BACKWARD = False
 
 
-def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, scale, stages=None, delta=None):
+def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, scale, stages=None, delta=None,
+                   scores=None):
     if stages is None:
         stages = 7 if DETERMINISTIC_ATTENTION_BACKWARD else 9
+    if stages & 8 and not stages & 48:
+        stages |= {128: 16, 256: 32}.get(ATTENTION_BACKWARD_KEYS, 0)
+    if not stages & 8:
+        scores = None
     B, H, I, D = q.shape
     J = k.shape[2]
     d_o = _as_kernel_view(d_o)
@@ -159,8 +186,9 @@ def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, sc
     L = _lib.load()
 
     def call(st):
-        rc = L.amk_attn_bwd(
-            _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(d_o),
+        fn, head = (L.amk_attn_bwd_kept, (_ptr(scores),)) if scores is not None and st & 8 else (L.amk_attn_bwd, ())
+        rc = fn(
+            *head, _ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(stats), _ptr(d_o),
             _ptr(dq), _ptr(dk), _ptr(dv), _ptr(delta), _ptr(key_mask), _ptr(causal_mask),
             B, H, I, J, D,
             *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(o), *_strides4(d_o),
@@ -171,7 +199,9 @@ def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, sc
 
     if KERNEL_EVENTS is not None and (stages & 1) and (stages & ~1):
         call(1)  # delta on its own so that the events bracket the main kernel(s) only
-        with _timed("attn_bwd_fused_kernel" if stages & 8 else "attn_bwd_dkdv+dq"):
+        name = "attn_bwd_dkdv+dq" if not stages & 8 else ("attn_bwd_fused_kernel(kept scores)" if scores is not None
+                                                            else "attn_bwd_fused_kernel")
+        with _timed(name):
             call(stages & ~1)
     else:
         call(stages)
@@ -182,20 +212,21 @@ class _AttnCore(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, key_mask, causal_mask, scale):
-        q, k, v, o, stats = _attn_forward(q, k, v, key_mask, causal_mask, scale)
-        ctx.save_for_backward(q, k, v, o, stats, key_mask, causal_mask)
+        need = any(ctx.needs_input_grad[:3])
+        q, k, v, o, stats, scores = _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=need)
+        ctx.save_for_backward(q, k, v, o, stats, key_mask, causal_mask, scores)
         ctx.scale = scale
         return o
 
     @staticmethod
     def backward(ctx, d_o):
-        q, k, v, o, stats, key_mask, causal_mask = ctx.saved_tensors
+        q, k, v, o, stats, key_mask, causal_mask, scores = ctx.saved_tensors
         B, H, I, D = q.shape
         J = k.shape[2]
         dq = _new_bthd(B, H, I, D, q)
         dk = _new_bthd(B, H, J, D, q)
         dv = _new_bthd(B, H, J, D, q)
-        _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, ctx.scale)
+        _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, ctx.scale, scores=scores)
         return dq, dk, dv, None, None, None
 
 
@@ -214,14 +245,15 @@ class _AttnFusedKV(torch.autograd.Function):
         kv = kv2.view(B, J, 2, H, D)
         k = kv[:, :, 0].permute(0, 2, 1, 3)
         v = kv[:, :, 1].permute(0, 2, 1, 3)
-        q, k, v, o, stats = _attn_forward(q, k, v, key_mask, causal_mask, scale)
-        ctx.save_for_backward(q, k, v, o, stats, key_mask, causal_mask)
+        need = any(ctx.needs_input_grad[:2])
+        q, k, v, o, stats, scores = _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=need)
+        ctx.save_for_backward(q, k, v, o, stats, key_mask, causal_mask, scores)
         ctx.scale = scale
         return o.permute(0, 2, 1, 3).reshape(B, I, H * D)
 
     @staticmethod
     def backward(ctx, d_o2):
-        q, k, v, o, stats, key_mask, causal_mask = ctx.saved_tensors
+        q, k, v, o, stats, key_mask, causal_mask, scores = ctx.saved_tensors
         B, H, I, D = q.shape
         J = k.shape[2]
         d_o = d_o2.contiguous().view(B, I, H, D).permute(0, 2, 1, 3)
@@ -231,7 +263,7 @@ class _AttnFusedKV(torch.autograd.Function):
         dkv = dkv2.view(B, J, 2, H, D)
         dk = dkv[:, :, 0].permute(0, 2, 1, 3)
         dv = dkv[:, :, 1].permute(0, 2, 1, 3)
-        _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, ctx.scale)
+        _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, ctx.scale, scores=scores)
         return dq2, dkv2, None, None, None, None, None
 
 

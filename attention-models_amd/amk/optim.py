@@ -1,0 +1,107 @@
+"""Adam / AdamW over the flat gradient buckets of amk.dp.GradReducer: global-norm clip, moment and
+parameter update and the zeroing of the gradients in two HBM passes (csrc/optim.hip), instead of
+``clip_grad_norm_`` + ``Adam.step`` + ``zero_grad`` (reference: trainers/vitgqgan.py:67-68,159-163,
+185-189; trainers/vit.py:29-31,74-76).
+
+The parameters themselves move into flat buffers laid out like the gradient buckets (``p.data``
+becomes a view), so one launch per bucket updates every parameter in it.  Parameters that received
+no gradient since the last step are skipped, as torch optimizers skip ``.grad is None``; step counts
+are kept per parameter for the bias corrections.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import lib as _lib
+from .dp import ALIGN
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+class FlatAdam:
+    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+        if not reducer.on_gpu:
+            raise RuntimeError("FlatAdam runs on MI355X (HIP) parameters only; use torch.optim on CPU")
+        self.red = reducer
+        self.lr, self.betas, self.eps, self.weight_decay, self.decoupled = lr, betas, eps, weight_decay, decoupled
+        self.L = _lib.load()
+        self.npart = self.L.amk_opt_num_partials()
+        dev = reducer.buckets[0].flat.device
+        self.params = [p for b in reducer.buckets for p in b.params]
+        self.steps = np.zeros(len(self.params), dtype=np.int64)
+        self.flat_p, self.m, self.v, self.seg = [], [], [], []
+        pid = 0
+        for b in reducer.buckets:
+            fp = torch.zeros_like(b.flat)
+            seg = torch.empty(b.flat.numel() // ALIGN, dtype=torch.int32)
+            for p, off in zip(b.params, b.offsets):
+                view = fp[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view  # the parameter now lives in the flat buffer
+                nseg = -(-p.numel() // ALIGN)
+                seg[off // ALIGN: off // ALIGN + nseg] = pid
+                pid += 1
+            self.flat_p.append(fp)
+            self.m.append(torch.zeros_like(b.flat))
+            self.v.append(torch.zeros_like(b.flat))
+            self.seg.append(seg.to(dev))
+        self.partials = torch.zeros(len(reducer.buckets) * self.npart, device=dev, dtype=torch.float32)
+        self.norm = torch.zeros(1, device=dev, dtype=torch.float32)
+        # per-step table {active, lr / bc1, sqrt(bc2), 0} per parameter: pinned host staging, async copy
+        self._tab_host = [torch.zeros(len(self.params), 4).pin_memory() for _ in range(2)]
+        self._tab_np = [t.numpy() for t in self._tab_host]  # views of the pinned buffers
+        self._tab_dev = [torch.zeros(len(self.params), 4, device=dev) for _ in range(2)]
+        self._tab_done = [None, None]
+        self._flip = 0
+
+    def step(self, max_norm=None, lr=None):
+        """One optimizer step on the (already reduced) gradients; leaves every gradient zeroed and
+        re-attached.  Returns the global gradient norm (device scalar, before clipping)."""
+        if lr is not None:
+            self.lr = lr
+        red, L = self.red, self.L
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        b1, b2 = self.betas
+        # double-buffered table: the copy of step n may still be in flight when step n+1 fills its table
+        tab_h, tab_d = self._tab_host[self._flip], self._tab_dev[self._flip]
+        if self._tab_done[self._flip] is not None:
+            self._tab_done[self._flip].synchronize()  # the copy issued two steps ago has read this host buffer
+        done = self._tab_done[self._flip] = torch.cuda.Event()
+        self._flip ^= 1
+        fired = np.fromiter((f for b in red.buckets for f in b.fired), dtype=bool, count=len(self.params))
+        self.steps += fired
+        t = np.maximum(self.steps, 1).astype(np.float64)
+        tab = self._tab_np[self._flip ^ 1]
+        tab[:, 0] = fired
+        tab[:, 1] = self.lr / (1.0 - b1 ** t)
+        tab[:, 2] = np.sqrt(1.0 - b2 ** t)
+        tab_d.copy_(tab_h, non_blocking=True)
+        done.record()
+        clip = float(max_norm) if max_norm else 0.0
+        for k, b in enumerate(red.buckets):
+            _lib.check(L.amk_sumsq_partials(_ptr(b.flat), b.flat.numel(), _ptr(self.partials[k * self.npart:]), stream),
+                       "amk_sumsq_partials")
+        for k, b in enumerate(red.buckets):
+            rc = L.amk_adam_flat_step(
+                _ptr(self.flat_p[k]), _ptr(b.flat), _ptr(self.m[k]), _ptr(self.v[k]), b.flat.numel(),
+                _ptr(self.seg[k]), _ptr(tab_d), _ptr(self.partials), self.partials.numel(),
+                clip, float(self.lr), float(b1), float(b2), float(self.eps), float(self.weight_decay),
+                1 if self.decoupled else 0, _ptr(self.norm) if k == 0 else _ptr(None), stream)
+            _lib.check(rc, "amk_adam_flat_step")
+        red.mark_zeroed()
+        return self.norm
+
+    # state in torch.optim.Adam's layout, for checkpoints / comparisons
+    def state_of(self, p):
+        k = next(i for i, q in enumerate(self.params) if q is p)
+        bi = 0
+        for b, m, v in zip(self.red.buckets, self.m, self.v):
+            if k < bi + len(b.params):
+                off = b.offsets[k - bi]
+                return dict(step=int(self.steps[k]), exp_avg=m[off:off + p.numel()].view_as(p),
+                            exp_avg_sq=v[off:off + p.numel()].view_as(p))
+            bi += len(b.params)
+        raise KeyError("parameter not managed by this optimizer")

@@ -15,6 +15,7 @@ import torch.nn.functional as F
 
 from .dp import GradReducer
 from .models.discriminator import input_grad_only
+from .optim import FlatAdam
 
 
 def set_requires_grad(module, flag):
@@ -43,16 +44,24 @@ class VQGANTrainStep:
     def __init__(self, model, discr, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0,
                  adv_loss_weight=0.1, logit_laplace_weight=1.0, max_grad_norm=1.0,
                  warmup_steps=50000, decay_steps=100000, gp_lambda=10.0, bucket_bytes=32 << 20,
-                 share_forward=False, capturable=False):
+                 share_forward=False, capturable=False, fused_optimizer=None):
         self.model, self.discr = model, discr
         self.adv_w, self.laplace_w = adv_loss_weight, logit_laplace_weight
         self.max_grad_norm, self.gp_lambda = max_grad_norm, gp_lambda
         self.base_lr, self.warmup_steps, self.decay_steps = lr, warmup_steps, decay_steps
         fused = next(model.parameters()).is_cuda
-        # capturable=True: the learning rate lives in a device tensor and the optimizer never reads
-        # device state on the host, so step_body() can be captured into a HIP graph (amk/graphs.py)
+        self.g_red = GradReducer(model.parameters(), bucket_bytes)
+        self.d_red = GradReducer(discr.parameters(), bucket_bytes)
+        # fused_optimizer (default on the GPU unless capturable): amk.optim.FlatAdam -- clip + Adam + zeroing in
+        # two passes over the reducer's flat buckets (csrc/optim.hip) instead of clip_grad_norm_ + Adam.step +
+        # zero_grad.  capturable=True: torch's Adam with the learning rate in a device tensor, so that
+        # step_body() can be captured into a HIP graph (amk/graphs.py).
+        self.fused_optimizer = (fused and not capturable) if fused_optimizer is None else bool(fused_optimizer)
         okw = dict(betas=betas, weight_decay=weight_decay, fused=fused)
-        if capturable:
+        if self.fused_optimizer:
+            self.g_optim = FlatAdam(self.g_red, lr=lr, betas=betas, weight_decay=weight_decay)
+            self.d_optim = FlatAdam(self.d_red, lr=lr, betas=betas, weight_decay=weight_decay)
+        elif capturable:
             dev = next(model.parameters()).device
             okw.update(capturable=True)
             self.g_optim = torch.optim.Adam(model.parameters(), lr=torch.tensor(float(lr), device=dev), **okw)
@@ -60,8 +69,6 @@ class VQGANTrainStep:
         else:
             self.g_optim = torch.optim.Adam(model.parameters(), lr=lr, **okw)
             self.d_optim = torch.optim.Adam(discr.parameters(), lr=lr, **okw)
-        self.g_red = GradReducer(model.parameters(), bucket_bytes)
-        self.d_red = GradReducer(discr.parameters(), bucket_bytes)
         self.g_red.broadcast_parameters()
         self.d_red.broadcast_parameters()
         self.global_step = 0
@@ -73,9 +80,10 @@ class VQGANTrainStep:
         # reference call for call.
         self.share_forward = bool(share_forward)
 
-    def gradient_penalty(self, real, fake):
-        """trainers/vitgqgan.py:115-131."""
-        eta = torch.rand(real.shape[0], 1, 1, 1, device=real.device)
+    def gradient_penalty(self, real, fake, eta=None):
+        """trainers/vitgqgan.py:115-131.  eta: the interpolation weights (drawn here unless given)."""
+        if eta is None:
+            eta = torch.rand(real.shape[0], 1, 1, 1, device=real.device)
         mixed = (eta * real + (1.0 - eta) * fake).detach().requires_grad_(True)
         pred = self.discr(mixed)
         with input_grad_only():   # only d pred / d mixed is asked for: skip the weight gradients
@@ -84,44 +92,57 @@ class VQGANTrainStep:
         return ((grad.norm(2, dim=1) - 1.0) ** 2).mean() * self.gp_lambda
 
     def _set_lr(self):
-        lr = cosine_warmup_lr(self.global_step, self.base_lr, self.decay_steps, self.warmup_steps)
+        # The reference steps its schedulers AFTER the optimizer, with the step index before the increment
+        # (trainers/vitgqgan.py:161-162,187-188,206), and timm's scheduler starts the optimizer at
+        # warmup_lr_init: step n therefore runs with schedule(n - 1), steps 0 and 1 both with schedule(0).
+        lr = cosine_warmup_lr(max(self.global_step - 1, 0), self.base_lr, self.decay_steps, self.warmup_steps)
         for opt in (self.g_optim, self.d_optim):
+            if isinstance(opt, FlatAdam):
+                opt.lr = lr
+                continue
             for g in opt.param_groups:
                 if torch.is_tensor(g["lr"]):
                     g["lr"].fill_(lr)
                 else:
                     g["lr"] = lr
 
-    def step(self, img, sync=True):
+    def step(self, img, sync=True, accum_steps=1, eta=None):
+        """sync=False: a gradient-accumulation micro-step (no communication, no optimizer step).
+        accum_steps: the losses are divided by it before backward, as accelerator.backward does with
+        gradient_accumulation_steps (the logged values stay undivided)."""
         self._set_lr()
-        logs = self.step_body(img, sync)
+        logs = self.step_body(img, sync, accum_steps, eta)
         self.global_step += 1
         return logs
 
-    def step_body(self, img, sync=True):
-        """Everything of a step that runs on the device (no host-side schedule): what a HIP graph captures."""
+    def _optim_step(self, opt, red, module):
+        if isinstance(opt, FlatAdam):
+            opt.step(max_norm=self.max_grad_norm)
+            return
+        if self.max_grad_norm:
+            torch.nn.utils.clip_grad_norm_(module.parameters(), self.max_grad_norm)
+        opt.step()
+        red.zero_grad()
+
+    def d_phase(self, img, sync=True, accum_steps=1, eta=None, rec=None):
+        """Discriminator phase (reference :146-163).  rec: a detached reconstruction to reuse (share_forward)."""
         model, discr = self.model, self.discr
-        # ---- discriminator phase (reference :146-163)
-        shared = None
-        if self.share_forward:
-            set_requires_grad(model, True)
-            shared = model(img)
-            rec = shared[0].detach()
-        else:
+        if rec is None:
             set_requires_grad(model, False)
         set_requires_grad(discr, True)
         self.d_red.begin(sync)
-        if shared is None:
+        if rec is None:
             rec, _ = model(img)
-        d_loss = hinge_d_loss(discr(rec), discr(img)) + self.gradient_penalty(img, rec)
-        d_loss.backward()
+        d_loss = hinge_d_loss(discr(rec), discr(img)) + self.gradient_penalty(img, rec, eta)
+        (d_loss if accum_steps == 1 else d_loss / accum_steps).backward()
         self.d_red.finish()
         if sync:
-            if self.max_grad_norm:
-                torch.nn.utils.clip_grad_norm_(discr.parameters(), self.max_grad_norm)
-            self.d_optim.step()
-            self.d_red.zero_grad()
-        # ---- generator phase (reference :167-189)
+            self._optim_step(self.d_optim, self.d_red, discr)
+        return d_loss.detach()
+
+    def g_phase(self, img, sync=True, accum_steps=1, shared=None):
+        """Generator phase (reference :167-189).  shared: (rec, codebook_loss) with its graph (share_forward)."""
+        model, discr = self.model, self.discr
         set_requires_grad(model, True)
         set_requires_grad(discr, False)
         self.g_red.begin(sync)
@@ -130,27 +151,49 @@ class VQGANTrainStep:
         l2 = F.mse_loss(rec, img)
         g_loss = g_nonsaturating_loss(discr(rec))
         loss = codebook_loss + self.adv_w * g_loss + self.laplace_w * l1 + l2
-        loss.backward()
+        (loss if accum_steps == 1 else loss / accum_steps).backward()
         self.g_red.finish()
         if sync:
-            if self.max_grad_norm:
-                torch.nn.utils.clip_grad_norm_(model.parameters(), self.max_grad_norm)
-            self.g_optim.step()
-            self.g_red.zero_grad()
-        return dict(d_loss=d_loss.detach(), g_loss=g_loss.detach(), l1=l1.detach(), l2=l2.detach(),
+            self._optim_step(self.g_optim, self.g_red, model)
+        return dict(g_loss=g_loss.detach(), l1=l1.detach(), l2=l2.detach(),
                     codebook_loss=codebook_loss.detach(), loss=loss.detach())
+
+    def step_body(self, img, sync=True, accum_steps=1, eta=None):
+        """Everything of a step that runs on the device (no host-side schedule): what a HIP graph captures."""
+        shared = None
+        if self.share_forward:
+            set_requires_grad(self.model, True)
+            shared = self.model(img)
+        d_loss = self.d_phase(img, sync, accum_steps, eta, rec=shared[0].detach() if shared is not None else None)
+        logs = self.g_phase(img, sync, accum_steps, shared)
+        logs["d_loss"] = d_loss
+        return logs
 
     # ---- checkpoints in the reference's format (trainers/utils/base_trainer.py:92-115)
     def save_ckpt(self, path, config=None):
         """{'step', 'state_dict', 'config'} with the generator's state_dict under the reference's key
         names, so either side can load the other's file (models/model_factory.py:14-17)."""
+        import torch.distributed as dist
+
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return  # one writer (the reference's accelerator.save is main-process only as well)
         ckpt = {"step": self.global_step,
                 "state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()},
                 "config": config}
         torch.save(ckpt, path)
 
     def resume_from_checkpoint(self, path):
-        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        import pickle
+
+        try:
+            ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        except pickle.UnpicklingError as e:
+            # a checkpoint written BY THE REFERENCE stores its OmegaConf DictConfig under 'config'
+            # (trainers/utils/base_trainer.py:92-107); the safe loader refuses such objects.
+            raise RuntimeError(
+                f"{path}: not loadable with weights_only=True ({e}). A reference-written checkpoint must have its "
+                "'config' entry converted to a plain dict (or dropped) first; only tensors and plain containers "
+                "are loaded here.") from e
         self.global_step = int(ckpt["step"])
         self.model.load_state_dict(ckpt["state_dict"])
         self.g_red.broadcast_parameters()

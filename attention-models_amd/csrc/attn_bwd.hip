@@ -376,7 +376,7 @@ using namespace amk_attn;
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool strides_ok(const Strides& s) { return (s.sb % 4 == 0) && (s.st % 4 == 0) && (s.sh % 4 == 0); }
 
-extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
+static int attn_bwd_impl(const float* scores, const float* q, const float* k, const float* v, const float* o,
                             const float* stats, const float* d_o,
                             float* dq, float* dk, float* dv, float* delta_ws,
                             const uint8_t* key_mask, const uint8_t* causal_mask,
@@ -404,6 +404,9 @@ extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, cons
   p.pinf = INFINITY;
   p.nqblk = (I + BLK - 1) / BLK;
   p.nkblk = (J + BLK - 1) / BLK;
+  p.scores = scores;
+  AMK_CHECK_ARG(!scores || aligned16(scores), "amk_attn_bwd_kept: the scores buffer must be 16-byte aligned");
+  AMK_CHECK_ARG(!scores || (stages & AMK_ATTN_BWD_FUSED), "amk_attn_bwd_kept: kept scores are read by the fused pass only");
   AMK_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o) && aligned16(dq) &&
                     aligned16(dk) && aligned16(dv) && strides_ok(p.qs) && strides_ok(p.ks) && strides_ok(p.vs) &&
                     strides_ok(p.os) && strides_ok(p.dos) && strides_ok(p.dqs) && strides_ok(p.dks) && strides_ok(p.dvs),
@@ -419,7 +422,8 @@ extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, cons
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, st, p);
   if (stages & AMK_ATTN_BWD_FUSED) {
     // one-pass kernel when the layout / masks allow it, else the two recompute kernels
-    if (launch_attn_bwd_fused(p, st)) stages &= ~(AMK_ATTN_BWD_DKDV | AMK_ATTN_BWD_DQ);
+    const int keys = (stages & AMK_ATTN_BWD_KEYS256) ? 256 : ((stages & AMK_ATTN_BWD_KEYS128) ? 128 : 0);
+    if (launch_attn_bwd_fused(p, keys, st)) stages &= ~(AMK_ATTN_BWD_DKDV | AMK_ATTN_BWD_DQ);
     else stages |= AMK_ATTN_BWD_DKDV | AMK_ATTN_BWD_DQ;
   }
   if (stages & AMK_ATTN_BWD_DKDV) {
@@ -432,4 +436,43 @@ extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, cons
   }
   AMK_CHECK_LAUNCH("amk_attn_bwd");
   return AMK_OK;
+}
+
+extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
+                            const float* stats, const float* d_o,
+                            float* dq, float* dk, float* dv, float* delta_ws,
+                            const uint8_t* key_mask, const uint8_t* causal_mask,
+                            int B, int H, int I, int J, int Dh,
+                            int64_t q_sb, int64_t q_st, int64_t q_sh,
+                            int64_t k_sb, int64_t k_st, int64_t k_sh,
+                            int64_t v_sb, int64_t v_st, int64_t v_sh,
+                            int64_t o_sb, int64_t o_st, int64_t o_sh,
+                            int64_t do_sb, int64_t do_st, int64_t do_sh,
+                            int64_t dq_sb, int64_t dq_st, int64_t dq_sh,
+                            int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
+                            int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
+                            float scale, int stages, void* stream) {
+  return attn_bwd_impl(nullptr, q, k, v, o, stats, d_o, dq, dk, dv, delta_ws, key_mask, causal_mask, B, H, I, J, Dh,
+                       q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh, do_sb, do_st, do_sh,
+                       dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh, scale, stages, stream);
+}
+
+extern "C" int amk_attn_bwd_kept(const float* scores, const float* q, const float* k, const float* v, const float* o,
+                                 const float* stats, const float* d_o,
+                                 float* dq, float* dk, float* dv, float* delta_ws,
+                                 const uint8_t* key_mask, const uint8_t* causal_mask,
+                                 int B, int H, int I, int J, int Dh,
+                                 int64_t q_sb, int64_t q_st, int64_t q_sh,
+                                 int64_t k_sb, int64_t k_st, int64_t k_sh,
+                                 int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                 int64_t o_sb, int64_t o_st, int64_t o_sh,
+                                 int64_t do_sb, int64_t do_st, int64_t do_sh,
+                                 int64_t dq_sb, int64_t dq_st, int64_t dq_sh,
+                                 int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
+                                 int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
+                                 float scale, int stages, void* stream) {
+  AMK_CHECK_ARG(scores, "amk_attn_bwd_kept: null scores buffer");
+  return attn_bwd_impl(scores, q, k, v, o, stats, d_o, dq, dk, dv, delta_ws, key_mask, causal_mask, B, H, I, J, Dh,
+                       q_sb, q_st, q_sh, k_sb, k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh, do_sb, do_st, do_sh,
+                       dq_sb, dq_st, dq_sh, dk_sb, dk_st, dk_sh, dv_sb, dv_st, dv_sh, scale, stages, stream);
 }

@@ -1,19 +1,22 @@
-// Fused softmax-attention backward for gfx950: ONE pass, five products, dQ by f32 atomics.
+// Fused softmax-attention backward for gfx950: ONE pass, dQ by f32 atomics.
 //
 // The two-kernel backward of attn_bwd.hip recomputes S twice and dP twice (7 products, bitwise
 // reproducible, no atomics).  This kernel computes each product once (cdna guide, Appendix B
-// "Attention backward"): a workgroup (4 waves) owns 128 keys of one (batch, head) -- v of a
+// "Attention backward"): a workgroup (NW waves) owns 32*NW keys of one (batch, head) -- v of a
 // wave's 32 keys lives in registers, the K block in LDS, dK^T / dV^T accumulate in registers -- and sweeps the
 // queries in tiles of 32:
 //
-//   S  = Q K^T, dP = dO V^T     32x32x2 MFMA, A = q / dO rows from LDS, B = k rows (LDS) / v registers
+//   S  = Q K^T                  32x32x2 MFMA (A = q rows from LDS, B = k rows from LDS) -- or, KEPT = true,
+//                               read back from the 32x32 score tiles the forward left in HBM
+//                               (amk_attn_fwd_keep; bitwise the same numbers): four products instead of five
+//   dP = dO V^T                 32x32x2 MFMA, A = dO rows from LDS, B = v registers
 //   P, dS                       key on the lane: fills are per-lane constants, row stats from LDS
 //   dV^T += dO^T P, dK^T += Q^T dS   A = dO / q columns from LDS, B = the accumulators as they stand
-//   dS -> LDS ([query][key], all 128 keys of the workgroup), one barrier, then
-//   dQ tile (32 x 64) = dS (32 x 128) K (128 x 64) with v_mfma_f32_16x16x4_f32: every wave owns two
-//        16x16 output blocks over ALL 128 keys, so no cross-wave reduction; the result is added
+//   dS -> LDS ([query][key], all keys of the workgroup), one barrier, then
+//   dQ tile (32 x 64) = dS (32 x 32NW) K (32NW x 64) with v_mfma_f32_16x16x4_f32: every wave owns 8/NW
+//        16x16 output blocks over ALL keys of the workgroup, so no cross-wave reduction; the result is added
 //        to dq with global_atomic_add_f32 (dq is zeroed by the launcher).  Atomic volume is
-//        8 KiB per (32 query x 128 key) tile = one byte per 320 FLOP.
+//        8 KiB per (32 query x 32NW key) tile: every dq element receives J / (32 NW) adds.
 // Two workgroup barriers per query tile (the next q / dO tile is committed under the dQ product);
 // workgroups start at rotated query tiles so that co-resident ones are not in the same phase.
 // Results differ from run to run in the last bits of dq only (f32 atomic arrival order); dk, dv are
@@ -23,8 +26,16 @@
 namespace amk_attn {
 
 constexpr int TQ = 32;             // queries per tile
-constexpr int DS_STRIDE = BLK + 4; // dS tile row stride (floats): 16-B aligned rows, b128 row reads
-constexpr int FUSED_LDS_FLOATS = 2 * TQ * LDS_STRIDE + BLK * LDS_STRIDE + TQ * DS_STRIDE + 3 * TQ;
+
+template <int NW>
+struct FusedGeom {
+  static constexpr int NT = 64 * NW;          // threads
+  static constexpr int KB = 32 * NW;          // keys per workgroup
+  static constexpr int DS_STRIDE = KB + 4;    // dS tile row stride (floats): 16-B aligned rows, b128 row reads
+  static constexpr int LDS_FLOATS = 2 * TQ * LDS_STRIDE + KB * LDS_STRIDE + TQ * DS_STRIDE + 3 * TQ;
+  static constexpr int NBLK = 8 / NW;         // 16x16 dQ blocks per wave
+  static constexpr int KPG = KB / 4;          // keys per k-group of the 16x16x4 product
+};
 
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   // D(16x16) += A(16x4) B(4x16): lane l supplies A[l & 15][l >> 4], B[l >> 4][l & 15];
@@ -32,25 +43,30 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-__global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
+template <int NW, bool KEPT>
+__global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p) {
+  using G = FusedGeom<NW>;
+  constexpr int NT = G::NT, KB = G::KB, DS_STRIDE = G::DS_STRIDE, KPG = G::KPG;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;                           // [TQ][LDS_STRIDE]  (q * scale * log2 e)
   float* Gs = Qs + TQ * LDS_STRIDE;           // [TQ][LDS_STRIDE]  dO
-  float* Kc = Gs + TQ * LDS_STRIDE;           // [BLK][LDS_STRIDE] this workgroup's K rows
-  float* dSl = Kc + BLK * LDS_STRIDE;         // [TQ][DS_STRIDE]   dS of the current tile
+  float* Kc = Gs + TQ * LDS_STRIDE;           // [KB][LDS_STRIDE]  this workgroup's K rows
+  float* dSl = Kc + KB * LDS_STRIDE;          // [TQ][DS_STRIDE]   dS of the current tile
   float* Ms = dSl + TQ * DS_STRIDE;
   float* Ls = Ms + TQ;
   float* Ds = Ls + TQ;
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  // wave-uniform by construction; readfirstlane tells the compiler (scalar registers, and no waterfall
+  // loop around the loads through the per-wave score-tile descriptor below)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ln = lane & 31, hf = lane >> 5;
 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int kb = wg % p.nkblk;
   const int bh = wg / p.nkblk;
   const int h = bh % p.H, b = bh / p.H;
-  const int kj = kb * BLK + wave * 32 + ln;  // this lane's key row
+  const int kj = kb * KB + wave * 32 + ln;  // this lane's key row
   const bool kvalid = kj < p.J;
 
   const float* kbase = p.k + (int64_t)b * p.ks.sb + (int64_t)h * p.ks.sh;
@@ -71,17 +87,17 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
   else if (p.key_mask && p.key_mask[(int64_t)b * p.J + kj] == 0) kfill = AMK_FILL_MASKED;
   const bool plain = __all(kfill == 0.f);  // wave-uniform: none of this wave's keys is filled
 
-  // K rows of the whole workgroup -> LDS once (B operand of the dQ product)
+  // K rows of the whole workgroup -> LDS once (B operand of the dQ product, and of S when it is recomputed)
   {
-    RowStagerT<BLK / 2> kl;  // two passes of 64 rows
-    const float* kblk = kbase + (int64_t)kb * BLK * p.ks.st;
-    kl.init(kblk, p.ks.st, min(BLK, p.J - kb * BLK), tid);
+    RowStagerT<KB / 2, NT> kl;  // two passes of KB/2 rows, 4 x 16 B per thread each
+    const float* kblk = kbase + (int64_t)kb * KB * p.ks.st;
+    kl.init(kblk, p.ks.st, min(KB, p.J - kb * KB), tid);
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       float4 t[4];
       kl.load(t);
 #pragma unroll
-      for (int ps = 0; ps < 4; ++ps) st4(&Kc[(64 * half + (tid >> 4) + 16 * ps) * LDS_STRIDE + (tid & 15) * 4], t[ps]);
+      for (int ps = 0; ps < 4; ++ps) st4(&Kc[((KB / 2) * half + (tid >> 4) + (NT / 16) * ps) * LDS_STRIDE + (tid & 15) * 4], t[ps]);
     }
   }
 
@@ -90,46 +106,78 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
   const float* stbase = p.stats + ((int64_t)b * p.H + h) * p.I * 2;
   const float* dlbase = p.delta + ((int64_t)b * p.H + h) * p.I;
   float* dqbase = p.dq + (int64_t)b * p.dqs.sb + (int64_t)h * p.dqs.sh;
+  // dq rows of this (batch, head) through a buffer descriptor: adds to rows beyond the sequence are
+  // dropped by the hardware range check, so the atomics need no branch either
+  const __amdgpu_buffer_rsrc_t dq_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)dqbase, 0, (int)(((int64_t)(p.I - 1) * p.dqs.st + 64) * 4), 0x00020000);
 
+  // kept scores: this wave's 32 keys x all query tiles are nqt consecutive 4-KiB tiles; a buffer
+  // descriptor of zero records (key block beyond the forward's tiles) reads zeros
+  __amdgpu_buffer_rsrc_t sc_rsrc;
+  int sc_voff = 0;
+  if (KEPT) {
+    const ScoreTiles stl(p.I, p.J);
+    const int kb32 = kb * NW + wave;
+    const float* tiles = p.scores + ((int64_t)bh * stl.nkb + min(kb32, stl.nkb - 1)) * stl.nqt * 1024;
+    sc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tiles, 0, kb32 < stl.nkb ? stl.nqt * 4096 : 0, 0x00020000);
+    sc_voff = ln * 128 + hf * 16;  // row = this lane's key, 4 queries of register group g at +32 g bytes
+  }
+  float4 sk[4];  // KEPT: the score registers of the coming tile (16 queries of this lane's key)
+  auto load_scores = [&](int qt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+      sk[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sc_rsrc, sc_voff + 32 * g, qt * 4096, 2));
+  };
+
+  constexpr int QNP = RowStagerT<TQ, NT>::NP;  // 16-B pieces per thread of a 32-row tile (2 or 1)
   const int srow = tid >> 4, scol = (tid & 15) * 4;
-  float4 qst[2], gst[2];
-  float mst = 0.f, lst = 0.f, dst = 0.f;
-  RowStagerT<TQ> qload, gload;
+  float4 qst[QNP], gst[QNP];
+  RowStagerT<TQ, NT> qload, gload;
   qload.init(qbase, p.qs.st, p.I, tid);
   gload.init(gbase, p.dos.st, p.I, tid);
-  auto prefetch = [&](int i0) {
+  // No branch around any vector-memory instruction of the tile loop: the compiler can then count, at
+  // every wait, how many younger loads / atomics are in flight (s_waitcnt vmcnt(N) with N > 0); behind a
+  // branch it must assume none and waits for everything, the dq atomics of the previous tile included.
+  float2 ml_raw = make_float2(0.f, 1.f);
+  float dl_raw = 0.f;
+  bool row_ok = false;
+  auto prefetch = [&](int i0) {  // loads only: whatever consumes them waits in commit(), a tile later
     qload.load(qst);
     gload.load(gst);
-    if (tid < TQ) {
-      const int i = i0 + tid;
-      if (i < p.I) {
-        mst = stbase[2 * i];
-        lst = 1.f / stbase[2 * i + 1];
-        dst = dlbase[i];
-      } else {  // rows beyond the sequence: P = exp2(x - inf) * 0 = 0
-        mst = INFINITY; lst = 0.f; dst = 0.f;
-      }
-    }
+    const int i = i0 + (tid & (TQ - 1));
+    const int ic = min(i, p.I - 1);
+    ml_raw = *reinterpret_cast<const float2*>(stbase + 2 * ic);
+    dl_raw = dlbase[ic];
+    row_ok = i < p.I;
   };
   auto commit = [&]() {
+    // Nothing below may be scheduled up to the loads (the compiler likes to): next to them it would sit
+    // on the memory latency; here the loads were issued a tile ago.
+    __builtin_amdgcn_sched_barrier(0);
     const float sc = p.scale * AMK_LOG2E;  // S comes out in the log2 domain; dK is scaled back by ln 2
 #pragma unroll
-    for (int ps = 0; ps < 2; ++ps) {
-      const int r = srow + 16 * ps;
+    for (int ps = 0; ps < QNP; ++ps) {
+      const int r = srow + (NT / 16) * ps;
       st4(&Qs[r * LDS_STRIDE + scol], make_float4(qst[ps].x * sc, qst[ps].y * sc, qst[ps].z * sc, qst[ps].w * sc));
       st4(&Gs[r * LDS_STRIDE + scol], gst[ps]);
     }
-    if (tid < TQ) { Ms[tid] = mst; Ls[tid] = lst; Ds[tid] = dst; }
+    // rows beyond the sequence: P = exp2(x - inf) * 0 = 0
+    if (tid < TQ) {  // LDS stores only
+      Ms[tid] = row_ok ? ml_raw.x : INFINITY;
+      Ls[tid] = row_ok ? 1.f / ml_raw.y : 0.f;
+      Ds[tid] = row_ok ? dl_raw : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
   };
 
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
 
   // dQ product geometry: 16x16x4 MFMA, lane = (column c = l & 15, k-group kg = l >> 4)
   const int c16 = lane & 15, kg = lane >> 4;
-  const int qhalf = wave & 1;        // which 16 of the tile's 32 queries
-  const int dcol0 = 32 * (wave >> 1); // this wave's 32 output columns (two 16-wide blocks)
-  const float* ds_row = &dSl[(16 * qhalf + c16) * DS_STRIDE + 32 * kg];  // A: dS[query][32*kg + s]
-  const float* kc_col = &Kc[(32 * kg) * LDS_STRIDE + dcol0 + c16];       // B: K[32*kg + s][dcol]
+  const int qhalf = wave & 1;                          // which 16 of the tile's 32 queries
+  const int dcol0 = (16 * G::NBLK) * (wave >> 1);      // this wave's output columns (NBLK 16-wide blocks)
+  const float* ds_row = &dSl[(16 * qhalf + c16) * DS_STRIDE + KPG * kg];  // A: dS[query][KPG*kg + s]
+  const float* kc_col = &Kc[(KPG * kg) * LDS_STRIDE + dcol0 + c16];       // B: K[KPG*kg + s][dcol]
 
   const int ntile = (p.I + TQ - 1) / TQ;
   // Two barriers per query tile.  After the dS barrier every wave is past the phases that read the
@@ -142,19 +190,23 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
   qload.seek(rot, p.qs.st, tid);
   gload.seek(rot, p.dos.st, tid);
   prefetch(rot * TQ);
+  if (KEPT) load_scores(rot);
   __syncthreads();  // the K block is in LDS
   commit();
   __syncthreads();
-  if (ntile > 1) {
-    const int nx = tile_of(1);
+  {
+    const int nx = tile_of(min(1, ntile - 1));
     qload.seek(nx, p.qs.st, tid);
     gload.seek(nx, p.dos.st, tid);
     prefetch(nx * TQ);
   }
+  // Enter the loop with nothing in flight: the waits inside are then the back edge's counted ones
+  // (one memory latency per workgroup here; vmcnt(0) with expcnt / lgkmcnt left alone).
+  __builtin_amdgcn_s_waitcnt(0x0F70);
   for (int t = 0; t < ntile; ++t) {
     const int i0 = tile_of(t) * TQ;
 
-    // ---- S and dP for the tile's 32 queries x this wave's 32 keys (2 x 32 MFMAs)
+    // ---- S and dP for the tile's 32 queries x this wave's 32 keys
     f32x16 s = zero16(), dp = zero16();
     {
       const float* qr = &Qs[ln * LDS_STRIDE + 32 * hf];
@@ -162,14 +214,25 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
       const float* kr = &Kc[(32 * wave + ln) * LDS_STRIDE + 32 * hf];  // this lane's key row
 #pragma unroll
       for (int s4 = 0; s4 < 8; ++s4) {
-        const float4 a = ld4(qr + 4 * s4);
         const float4 c = ld4(gr + 4 * s4);
-        const float4 kk = ld4(kr + 4 * s4);
+        if (!KEPT) {
+          const float4 a = ld4(qr + 4 * s4);
+          const float4 kk = ld4(kr + 4 * s4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          s = mfma32(f4(a, e), f4(kk, e), s);
-          dp = mfma32(f4(c, e), vreg[4 * s4 + e], dp);
+          for (int e = 0; e < 4; ++e) {
+            s = mfma32(f4(a, e), f4(kk, e), s);
+            dp = mfma32(f4(c, e), vreg[4 * s4 + e], dp);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dp = mfma32(f4(c, e), vreg[4 * s4 + e], dp);
         }
+      }
+    }
+    if (KEPT) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        s[4 * g + 0] = sk[g].x; s[4 * g + 1] = sk[g].y; s[4 * g + 2] = sk[g].z; s[4 * g + 3] = sk[g].w;
       }
     }
     // ---- P and dS (register r of this lane is query acc_row(r, hf))
@@ -218,45 +281,49 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
       dk0 = mfma32(qc[0], dp[r], dk0);
       dk1 = mfma32(qc[32], dp[r], dk1);
     }
+    // the score registers are free: fetch the next tile's (consumed after the next tile's dP product;
+    // the last iteration re-reads its own tile, unused)
+    if (KEPT) load_scores(tile_of(min(t + 1, ntile - 1)));
     __syncthreads();  // every wave's dS columns are in LDS; the q / dO / stats tiles are dead
-    if (t + 1 < ntile) {
-      commit();
-      if (t + 2 < ntile) {
-        const int nx = tile_of(t + 2);
-        qload.seek(nx, p.qs.st, tid);
-        gload.seek(nx, p.dos.st, tid);
-        prefetch(nx * TQ);
-      }
+    commit();         // (the last iteration commits a tile nobody reads)
+    {
+      const int nx = tile_of(min(t + 2, ntile - 1));
+      qload.seek(nx, p.qs.st, tid);
+      gload.seek(nx, p.dos.st, tid);
+      prefetch(nx * TQ);
     }
 
-    // ---- dQ (16 queries x 32 columns per wave) = dS (16 x 128) K (128 x 32): 64 MFMAs 16x16x4
+    // ---- dQ (16 queries x 16*NBLK columns per wave) = dS (16 x KB) K (KB x 16*NBLK): 64 MFMAs 16x16x4,
+    //      two independent accumulator chains either way (two blocks, or even / odd k-steps of one)
     f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s4 = 0; s4 < 8; ++s4) {
+    for (int s4 = 0; s4 < KPG / 4; ++s4) {
       const float4 a = ld4(ds_row + 4 * s4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float* kc = kc_col + (4 * s4 + e) * LDS_STRIDE;
-        q0 = mfma16(f4(a, e), kc[0], q0);
-        q1 = mfma16(f4(a, e), kc[16], q1);
+        if (G::NBLK == 2) {
+          q0 = mfma16(f4(a, e), kc[0], q0);
+          q1 = mfma16(f4(a, e), kc[16], q1);
+        } else if (e & 1) {
+          q1 = mfma16(f4(a, e), kc[0], q1);
+        } else {
+          q0 = mfma16(f4(a, e), kc[0], q0);
+        }
       }
     }
     {
       const float sc = p.scale;
       const int qi0 = i0 + 16 * qhalf + 4 * kg;
-      float* dst_ = dqbase + (int64_t)qi0 * p.dqs.st + dcol0 + c16;
-      if (qi0 + 3 < p.I) {  // all four rows of this lane inside the sequence (the common case)
+      const int off = (int)(((int64_t)qi0 * p.dqs.st + dcol0 + c16) * 4);
+      const int rstep = (int)(p.dqs.st * 4);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          atomicAdd(dst_ + (int64_t)r * p.dqs.st, q0[r] * sc);
-          atomicAdd(dst_ + (int64_t)r * p.dqs.st + 16, q1[r] * sc);
-        }
-      } else {
-        for (int r = 0; r < 4; ++r) {
-          if (qi0 + r < p.I) {
-            atomicAdd(dst_ + (int64_t)r * p.dqs.st, q0[r] * sc);
-            atomicAdd(dst_ + (int64_t)r * p.dqs.st + 16, q1[r] * sc);
-          }
+      for (int r = 0; r < 4; ++r) {
+        if (G::NBLK == 2) {
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(q0[r] * sc, dq_rsrc, off + r * rstep, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(q1[r] * sc, dq_rsrc, off + r * rstep + 64, 0, 0);
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((q0[r] + q1[r]) * sc, dq_rsrc, off + r * rstep, 0, 0);
         }
       }
     }
@@ -276,19 +343,30 @@ __global__ __launch_bounds__(WG, 2) void attn_bwd_fused_kernel(BwdParams p) {
   }
 }
 
-// Launch the fused kernel.  dq must be the dense (B, I, H, 64) layout so that it can be zeroed
-// with one memset; returns false (nothing launched) when the layout or the masks rule it out.
-bool launch_attn_bwd_fused(const BwdParams& p, hipStream_t st) {
-  if (p.causal_mask) return false;
-  if (!(p.dqs.sh == D && p.dqs.st == (int64_t)p.H * D && p.dqs.sb == (int64_t)p.I * p.H * D)) return false;
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel),
+template <int NW, bool KEPT>
+static bool launch_variant(BwdParams p, hipStream_t st) {
+  using G = FusedGeom<NW>;
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NW, KEPT>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                  FUSED_LDS_FLOATS * (int)sizeof(float)) == hipSuccess;
+                                                  G::LDS_FLOATS * (int)sizeof(float)) == hipSuccess;
   if (!attr_ok) return false;
   if (hipMemsetAsync(p.dq, 0, (size_t)p.B * p.I * p.H * D * sizeof(float), st) != hipSuccess) return false;
+  p.nkblk = (p.J + G::KB - 1) / G::KB;
   const int64_t nk = (int64_t)p.B * p.H * p.nkblk;
-  hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3((unsigned)nk), dim3(WG), FUSED_LDS_FLOATS * sizeof(float), st, p);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<NW, KEPT>), dim3((unsigned)nk), dim3(G::NT), G::LDS_FLOATS * sizeof(float), st, p);
   return true;
+}
+
+// Launch the fused kernel.  dq must be the dense (B, I, H, 64) layout so that it can be zeroed
+// with one memset; returns false (nothing launched) when the layout or the masks rule it out.
+// keys_per_wg: 128 (4 waves, two workgroups per CU) or 256 (8 waves, one per CU; half the dq atomics);
+// 0 = pick (256 when the sequence has at least 256 keys).
+bool launch_attn_bwd_fused(const BwdParams& p, int keys_per_wg, hipStream_t st) {
+  if (p.causal_mask) return false;
+  if (!(p.dqs.sh == D && p.dqs.st == (int64_t)p.H * D && p.dqs.sb == (int64_t)p.I * p.H * D)) return false;
+  if (keys_per_wg == 0) keys_per_wg = p.J >= 256 ? 256 : 128;
+  if (keys_per_wg == 256) return p.scores ? launch_variant<8, true>(p, st) : launch_variant<8, false>(p, st);
+  return p.scores ? launch_variant<4, true>(p, st) : launch_variant<4, false>(p, st);
 }
 
 }  // namespace amk_attn

@@ -32,6 +32,7 @@ struct FwdParams {
   float pinf;  // +infinity, passed at run time (see vmax)
   int nblk;  // ceil(I / BLK)
   void* x6_ws;  // split-bf16 forward: K / V planes, B*H*ceil(J/64) tiles of 48 KiB (attn_fwd_x6.hip)
+  float* scores;  // kept scores (see ScoreTiles) or null
 };
 
 struct BwdParams {
@@ -43,6 +44,19 @@ struct BwdParams {
   float scale;
   float pinf;  // +infinity, passed at run time (see vmax)
   int nqblk, nkblk;  // ceil(I / BLK), ceil(J / BLK)
+  const float* scores;  // kept scores of the forward (see ScoreTiles) or null: S is recomputed
+};
+
+// Kept scores: the forward can leave S^T = (q*scale*log2e) k^T (before any fill) in HBM for the backward,
+// which then skips its fifth product.  Layout: 32x32 tiles of 4 KiB, [b][h][key block of 32][query
+// block of 32][key][query] -- the forward (query on the lane) stores 128 contiguous bytes per
+// half-wave and register, the backward (key on the lane) reads its 16 queries of one key as four
+// 16-byte pieces of one 128-byte line, and a backward wave walks consecutive tiles.
+// Both counts are padded to what the forward's workgroups cover (128 queries, 64-key tiles).
+struct ScoreTiles {
+  int nqt, nkb;
+  __host__ __device__ ScoreTiles(int I, int J) : nqt(4 * ((I + 127) / 128)), nkb(2 * ((J + 63) / 64)) {}
+  __host__ __device__ int64_t floats(int B, int H) const { return (int64_t)B * H * nkb * nqt * 1024; }
 };
 
 // max without the canonicalising v_max the compiler puts in front of fmaxf on MFMA outputs:
@@ -60,14 +74,15 @@ __device__ __forceinline__ f32x16 zero16() {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// Streams ROWS rows x 64 floats of one (batch, head) operand, global -> registers, 4 x 16 B per
-// thread (row = tid/16 + 16*pass, 16 B at column 4*(tid%16)), through a raw buffer descriptor:
+// Streams ROWS rows x 64 floats of one (batch, head) operand, global -> registers, 16 B per thread
+// and pass (row = tid/16 + (NT/16)*pass, 16 B at column 4*(tid%16)), through a raw buffer descriptor:
 // the hardware range check returns zeros for rows beyond the sequence, so a tile costs four
 // address adds and no compares / selects / 64-bit multiplies (every VALU instruction is paid
 // at ~4 cycles against the f32 MFMA pipe: tools/ubench_mfma_valu.hip).
-template <int ROWS>
+template <int ROWS, int NT = 256>
 struct RowStagerT {
-  static constexpr int NP = ROWS / 16;
+  static constexpr int RP = NT / 16;    // rows covered by one pass of the workgroup's NT threads
+  static constexpr int NP = ROWS / RP;
   __amdgpu_buffer_rsrc_t rsrc;
   int voff[NP];
   int step;
@@ -76,7 +91,7 @@ struct RowStagerT {
     rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(((int64_t)(nrows - 1) * row_stride + 64) * 4), 0x00020000);
     const int srow = tid >> 4, scol = (tid & 15) * 4;
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) voff[ps] = (int)(((int64_t)(srow + 16 * ps) * row_stride + scol) * 4);
+    for (int ps = 0; ps < NP; ++ps) voff[ps] = (int)(((int64_t)(srow + RP * ps) * row_stride + scol) * 4);
     step = (int)(ROWS * row_stride * 4);
   }
   __device__ __forceinline__ void load(float4 (&dst)[NP]) {
@@ -92,7 +107,7 @@ struct RowStagerT {
   __device__ __forceinline__ void seek(int blk, int64_t row_stride, int tid) {
     const int srow = tid >> 4, scol = (tid & 15) * 4;
 #pragma unroll
-    for (int ps = 0; ps < NP; ++ps) voff[ps] = (int)(((int64_t)(srow + 16 * ps) * row_stride + scol) * 4) + blk * step;
+    for (int ps = 0; ps < NP; ++ps) voff[ps] = (int)(((int64_t)(srow + RP * ps) * row_stride + scol) * 4) + blk * step;
   }
 };
 typedef RowStagerT<TILE> RowStager;
@@ -107,6 +122,6 @@ __device__ __forceinline__ float f4(const float4& v, int e) {
 void launch_attn_fwd_x6(const FwdParams& p, int64_t nwg, hipStream_t st);
 
 // attn_bwd_fused.hip: one-pass backward (dQ by atomics); false = not applicable, nothing launched.
-bool launch_attn_bwd_fused(const BwdParams& p, hipStream_t st);
+bool launch_attn_bwd_fused(const BwdParams& p, int keys_per_wg, hipStream_t st);
 
 }  // namespace amk_attn

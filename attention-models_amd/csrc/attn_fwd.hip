@@ -20,7 +20,7 @@
 
 namespace amk_attn {
 
-template <bool CAUSAL, bool SCHED>
+template <bool CAUSAL, bool SCHED, bool KEEP>
 __global__ __launch_bounds__(WG, 2) void attn_fwd_kernel(FwdParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * TILE * LDS_STRIDE + TILE];
   float* Ks = smem;
@@ -92,6 +92,13 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_kernel(FwdParams p) {
   f32x16 o0 = zero16(), o1 = zero16();
   float m_run = -INFINITY, l_run = 0.f;
 
+  // KEEP: S^T leaves for the backward as 32x32 tiles [key][query] (ScoreTiles): register r of this
+  // lane is key acc_row(r, hf) of query ln, so a half-wave stores 128 contiguous bytes per register.
+  const ScoreTiles stl(p.I, p.J);
+  const int64_t sc_kstep = (int64_t)stl.nqt * 1024;  // floats between consecutive 32-key blocks
+  float* sc_ptr = nullptr;
+  if (KEEP) sc_ptr = p.scores + ((int64_t)bh * stl.nkb * stl.nqt + (qb * NWAVE + wave)) * 1024 + 4 * hf * 32 + ln;
+
   const int ntile = (p.J + TILE - 1) / TILE;
   prefetch(0);
   for (int t = 0; t < ntile; ++t) {
@@ -141,6 +148,15 @@ __global__ __launch_bounds__(WG, 2) void attn_fwd_kernel(FwdParams p) {
         }
         a0 = n0;
         a1 = n1;
+      }
+    }
+    if (KEEP) {  // the raw scores (log2 domain, before any fill): what the backward would recompute
+      float* t0 = sc_ptr + (int64_t)(2 * t) * sc_kstep;
+      float* t1 = t0 + sc_kstep;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        __builtin_nontemporal_store(s0[r], t0 + acc_row(r, 0) * 32);
+        __builtin_nontemporal_store(s1[r], t1 + acc_row(r, 0) * 32);
       }
     }
     // ---- fills and online softmax (lane-local + one cross-half exchange) ----
@@ -253,7 +269,7 @@ using namespace amk_attn;
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool strides_ok(const Strides& s) { return (s.sb % 4 == 0) && (s.st % 4 == 0) && (s.sh % 4 == 0); }
 
-static int attn_fwd_impl(void* x6_ws, bool x6, const float* q, const float* k, const float* v, float* o, float* stats,
+static int attn_fwd_impl(void* x6_ws, bool x6, float* scores, const float* q, const float* k, const float* v, float* o, float* stats,
                          const uint8_t* key_mask, const uint8_t* causal_mask,
                          int B, int H, int I, int J, int Dh,
                          int64_t q_sb, int64_t q_st, int64_t q_sh,
@@ -273,6 +289,8 @@ static int attn_fwd_impl(void* x6_ws, bool x6, const float* q, const float* k, c
   p.pinf = INFINITY;
   p.nblk = (I + BLK - 1) / BLK;
   p.x6_ws = x6_ws;
+  p.scores = scores;
+  AMK_CHECK_ARG(!scores || aligned16(scores), "amk_attn_fwd_keep: the scores buffer must be 16-byte aligned");
   AMK_CHECK_ARG(!x6 || (x6_ws && aligned16(x6_ws)), "amk_attn_fwd_x6: workspace missing or not 16-byte aligned");
   AMK_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && strides_ok(p.qs) &&
                     strides_ok(p.ks) && strides_ok(p.vs) && strides_ok(p.os),
@@ -284,10 +302,14 @@ static int attn_fwd_impl(void* x6_ws, bool x6, const float* q, const float* k, c
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (x6)
     launch_attn_fwd_x6(p, nwg, st);
+  else if (causal_mask && scores)
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   else if (causal_mask)
-    hipLaunchKernelGGL((attn_fwd_kernel<true, false>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<true, false, false>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
+  else if (scores)
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   else
-    hipLaunchKernelGGL((attn_fwd_kernel<false, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<false, true, false>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   AMK_CHECK_LAUNCH("amk_attn_fwd");
   return AMK_OK;
 }
@@ -300,8 +322,26 @@ extern "C" int amk_attn_fwd(const float* q, const float* k, const float* v, floa
                             int64_t v_sb, int64_t v_st, int64_t v_sh,
                             int64_t o_sb, int64_t o_st, int64_t o_sh,
                             float scale, void* stream) {
-  return attn_fwd_impl(nullptr, false, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
+  return attn_fwd_impl(nullptr, false, nullptr, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
                        v_sb, v_st, v_sh, o_sb, o_st, o_sh, scale, stream);
+}
+
+extern "C" int64_t amk_attn_scores_bytes(int B, int H, int I, int J) {
+  if (B <= 0 || H <= 0 || I <= 0 || J <= 0) return 0;
+  return ScoreTiles(I, J).floats(B, H) * (int64_t)sizeof(float);
+}
+
+extern "C" int amk_attn_fwd_keep(const float* q, const float* k, const float* v, float* o, float* stats, float* scores,
+                                 const uint8_t* key_mask, const uint8_t* causal_mask,
+                                 int B, int H, int I, int J, int Dh,
+                                 int64_t q_sb, int64_t q_st, int64_t q_sh,
+                                 int64_t k_sb, int64_t k_st, int64_t k_sh,
+                                 int64_t v_sb, int64_t v_st, int64_t v_sh,
+                                 int64_t o_sb, int64_t o_st, int64_t o_sh,
+                                 float scale, void* stream) {
+  AMK_CHECK_ARG(scores, "amk_attn_fwd_keep: null scores buffer");
+  return attn_fwd_impl(nullptr, false, scores, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb,
+                       k_st, k_sh, v_sb, v_st, v_sh, o_sb, o_st, o_sh, scale, stream);
 }
 
 extern "C" int64_t amk_attn_fwd_x6_ws_bytes(int B, int H, int J) {
@@ -317,6 +357,6 @@ extern "C" int amk_attn_fwd_x6(const float* q, const float* k, const float* v, f
                                int64_t v_sb, int64_t v_st, int64_t v_sh,
                                int64_t o_sb, int64_t o_st, int64_t o_sh,
                                float scale, void* stream) {
-  return attn_fwd_impl(ws, true, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
+  return attn_fwd_impl(ws, true, nullptr, q, k, v, o, stats, key_mask, causal_mask, B, H, I, J, Dh, q_sb, q_st, q_sh, k_sb, k_st, k_sh,
                        v_sb, v_st, v_sh, o_sb, o_st, o_sh, scale, stream);
 }

@@ -1,6 +1,7 @@
 """ViT-VQGAN 256px training-step throughput on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus N ...          (no launcher: this process starts the N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -81,25 +82,36 @@ def kernel_rooflines(B, dev, iters):
     mk = lambda: torch.randn(B, T, H, D, generator=g).to(dev).permute(0, 2, 1, 3)  # (B,T,h*d) storage
     q, k, v, d_o = mk(), mk(), mk(), mk()
     scale = D ** -0.5
-    q, k, v, o, stats = ops._attn_forward(q, k, v, None, None, scale)
+    q, k, v, o, stats, scores = ops._attn_forward(q, k, v, None, None, scale, keep_scores=True)
     dq, dk, dv = (torch.empty_like(q) for _ in range(3))
     delta = torch.empty(B, H, T, device=dev)
-    bwd = lambda st: ops._attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, None, None, scale, stages=st, delta=delta)
+    bwd = lambda st, sc=None: ops._attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, None, None, scale, stages=st,
+                                                 delta=delta, scores=sc)
     bwd(1)
     core = 4.0 * B * H * T * T * D  # algorithmic FLOP of the forward
     layers_f, layers_b = 4 * VIT["depth"], 2 * VIT["depth"]  # per step: 2 model fwd + 1 bwd, enc+dec
     out = []
     t = time_launches(lambda: ops._attn_forward(q, k, v, None, None, scale), iters)
-    out.append(dict(kernel="attn_fwd_kernel", launches_per_step=layers_f, avg_ms=t * 1e3, flop=core,
+    out.append(dict(kernel="attn_fwd_kernel", launches_per_step=layers_f - layers_b, avg_ms=t * 1e3, flop=core,
                     note="4*B*h*I*J*d"))
+    if scores is not None:
+        t = time_launches(lambda: ops._attn_forward(q, k, v, None, None, scale, keep_scores=True), iters)
+        out.append(dict(kernel="attn_fwd_keep_kernel", launches_per_step=layers_b, avg_ms=t * 1e3, flop=core,
+                        note="4*B*h*I*J*d; also writes the raw scores (4*B*h*I*J bytes) for the backward"))
     old_mode, ops.ATTENTION_FORWARD = ops.ATTENTION_FORWARD, "bf16x6"
     t = time_launches(lambda: ops._attn_forward(q, k, v, None, None, scale), iters)
     ops.ATTENTION_FORWARD = old_mode
     out.append(dict(kernel="attn_fwd_x6 (split pre-pass + kernel)", launches_per_step=0, avg_ms=t * 1e3, flop=core,
                     note="the forward with split-bf16 products (amk_attn_fwd_x6); its bound is the bf16 MFMA peak / 6, "
                          "not the f32 MFMA peak the fraction below is taken against"))
+    if scores is not None:
+        t = time_launches(lambda: bwd(8, scores), iters)
+        out.append(dict(kernel="attn_bwd_fused_kernel(kept scores)", launches_per_step=layers_b, avg_ms=t * 1e3,
+                        flop=2 * core, note="8*B*h*I*J*d (dV,dP,dQ,dK: the four products it runs; S is read back from "
+                                            "the forward's score tiles); includes the dq memset"))
     t = time_launches(lambda: bwd(8), iters)
-    out.append(dict(kernel="attn_bwd_fused_kernel", launches_per_step=layers_b, avg_ms=t * 1e3, flop=2 * core,
+    out.append(dict(kernel="attn_bwd_fused_kernel", launches_per_step=0 if scores is not None else layers_b,
+                    avg_ms=t * 1e3, flop=2 * core,
                     note="8*B*h*I*J*d (dV,dP,dQ,dK; recomputed S not credited); includes the dq memset"))
     t = time_launches(lambda: bwd(2), iters)
     out.append(dict(kernel="attn_bwd_dkdv_kernel", launches_per_step=0, avg_ms=t * 1e3, flop=core,
@@ -120,8 +132,45 @@ def kernel_rooflines(B, dev, iters):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: start the N rank processes from here.  The parent
+    never touches HIP (no torch.cuda call), passes its own flags through, relays rank 0's JSON line and
+    fails if any rank fails.  (The driver's torch.distributed.run launch sets WORLD_SIZE and skips this.)"""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    if any(rcs):
+        raise SystemExit(f"bench.py: rank exit codes {rcs}")
+
+
+def latest_pmc_digest():
+    """Newest committed PMC digest (profiles/rNN_pmc_kernels_b32.json) or (None, None)."""
+    import glob
+
+    paths = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_kernels_b*.json")))
+    if not paths:
+        return None, None
+    return json.load(open(paths[-1])), os.path.relpath(paths[-1], ROOT)
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,6 +190,7 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    n_ranks_seen = dist.get_world_size() if world > 1 else 1
 
     from amk import lib
     from amk.models import ViTVQGAN
@@ -167,21 +217,22 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from amk import ops as amk_ops
+
+    def timed_steps(n):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            logs = trainer.step(imgs)
+        sync()
+        return time.perf_counter() - t0, logs
+
     note(f"rank {rank}/{world}: model built, batch {args.batch}/GPU")
     for _ in range(args.warmup):
         trainer.step(imgs)
-    sync()
     note("warm-up done")
-    from amk import ops as amk_ops
-    if rank == 0:
-        amk_ops.KERNEL_EVENTS = {}  # HIP events around every hot-path launch of the timed steps
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        logs = trainer.step(imgs)
-    sync()
-    dt = time.perf_counter() - t0
-    in_situ = amk_ops.kernel_event_summary(amk_ops.KERNEL_EVENTS) if rank == 0 else {}
-    amk_ops.KERNEL_EVENTS = None
+    # ---- the headline: EXACTLY --steps steps, no instrumentation, barrier + synchronize on both sides
+    dt, logs = timed_steps(args.steps)
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -189,42 +240,42 @@ def main():
     loss = float(logs["loss"])
     note(f"timed {args.steps} steps in {dt:.3f}s")
 
-    # informational variant (never `value`): the same step with the generator forward shared by the
-    # two phases (VQGANTrainStep(share_forward=True); identical numbers while dropout is 0)
-    shared = None
-    if world == 1 and not args.no_variants:
-        trainer.share_forward = True
+    # ---- a separate short instrumented pass (rank 0): HIP events on the launch stream around every
+    # hot-path launch of real train steps -> the in-step kernel figures of `roofline` / `kernels_in_step`
+    in_situ, n_inst = {}, 0
+    if rank == 0 and world == 1 and not args.no_kernels:
+        n_inst = max(2, min(5, args.steps))
+        amk_ops.KERNEL_EVENTS = {}
+        timed_steps(n_inst)
+        in_situ = amk_ops.kernel_event_summary(amk_ops.KERNEL_EVENTS)
+        amk_ops.KERNEL_EVENTS = None
+        note("instrumented pass done")
+
+    def variant(setup, teardown, what):
+        setup()
         for _ in range(2):
             trainer.step(imgs)
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            trainer.step(imgs)
-        sync()
-        ds = time.perf_counter() - t1
-        trainer.share_forward = False
-        shared = {"value": args.batch * args.steps / ds, "unit": "images/s", "ms_per_step": ds / args.steps * 1e3,
-                  "what": "generator forward run once per step and shared by the discriminator and generator "
-                          "phases (the reference runs it twice on unchanged weights); not the headline value"}
+        dv, _ = timed_steps(args.steps)
+        teardown()
+        return {"value": args.batch * args.steps / dv, "unit": "images/s", "ms_per_step": dv / args.steps * 1e3, "what": what}
+
+    variants = {}
+    if world == 1 and not args.no_variants:
+        # informational variants, never `value`
+        variants["variant_shared_generator_forward"] = variant(
+            lambda: setattr(trainer, "share_forward", True), lambda: setattr(trainer, "share_forward", False),
+            "generator forward run once per step and shared by the discriminator and generator phases (the "
+            "reference runs it twice on unchanged weights); not the headline value")
         note("shared-forward variant done")
-    # informational variant (never `value`): the reference-shaped step with the attention FORWARD on split-bf16
-    # products (amk_attn_fwd_x6: f32 operands, six exact bf16 partial products per product, f32 accumulation;
-    # measured error below the f32 MFMA path's).  The headline keeps the exact-f32 MFMA forward.
-    x6 = None
-    if world == 1 and not args.no_variants:
-        prev_mode, amk_ops.ATTENTION_FORWARD = amk_ops.ATTENTION_FORWARD, "bf16x6"
-        for _ in range(2):
-            trainer.step(imgs)
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            trainer.step(imgs)
-        sync()
-        dx = time.perf_counter() - t1
-        amk_ops.ATTENTION_FORWARD = prev_mode
-        x6 = {"value": args.batch * args.steps / dx, "unit": "images/s", "ms_per_step": dx / args.steps * 1e3,
-              "what": "attention forward with split-bf16 (bf16x6) products, f32-level error; backward and everything "
-                      "else as in the headline; not the headline value"}
+        variants["variant_recomputed_scores"] = variant(
+            lambda: setattr(amk_ops, "ATTENTION_KEEP_SCORES", False), lambda: setattr(amk_ops, "ATTENTION_KEEP_SCORES", True),
+            "the headline step with the attention backward recomputing S = QK^T (five products) instead of reading "
+            "the scores the forward kept in HBM (four products); identical results")
+        note("recomputed-scores variant done")
+        variants["variant_split_bf16_attention_forward"] = variant(
+            lambda: setattr(amk_ops, "ATTENTION_FORWARD", "bf16x6"), lambda: setattr(amk_ops, "ATTENTION_FORWARD", "f32"),
+            "attention forward with split-bf16 (bf16x6) products, f32-level error; the backward then recomputes S; "
+            "not the headline value")
         note("split-bf16 forward variant done")
 
     kernels = None
@@ -246,6 +297,7 @@ def main():
             "value": global_batch * args.steps / dt,
             "unit": "images/s",
             "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -265,49 +317,40 @@ def main():
                 "final_loss": loss,
             },
         }
-        # in-situ figures: HIP events on the launch stream, over the timed steps themselves
         T_ = (VIT["img_size"] // VIT["patch_size"]) ** 2
         core = 4.0 * args.batch * VIT["n_heads"] * T_ * T_ * VIT["d_head"]
-        flop_of = {"attn_fwd_kernel": core, "attn_bwd_fused_kernel": 2 * core, "attn_bwd_dkdv+dq": 2 * core,
+        flop_of = {"attn_fwd_kernel": core, "attn_fwd_keep_kernel": core, "attn_bwd_fused_kernel": 2 * core,
+                   "attn_bwd_fused_kernel(kept scores)": 2 * core, "attn_bwd_dkdv+dq": 2 * core,
                    "vq_lookup_fwd": 2.0 * args.batch * T_ * CODEBOOK["codebook_size"] * CODEBOOK["codebook_dim"]}
         timed = []
         for name, (n, ms) in in_situ.items():
             fl = flop_of.get(name)
-            timed.append(dict(kernel=name, launches_per_step=n / args.steps, avg_ms=ms, flop=fl,
+            if fl is None:
+                continue
+            timed.append(dict(kernel=name, launches_per_step=n / n_inst, avg_ms=ms, flop=fl,
                               tflops=fl / (ms * 1e-3) / 1e12, frac_of_f32_mfma_peak=fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS,
-                              ms_per_step=ms * n / args.steps))
+                              ms_per_step=ms * n / n_inst))
+        source = "HIP events on the launch stream around every launch of this kernel in %d instrumented train steps" % n_inst
+        if not timed and kernels:
+            timed = [r for r in kernels if r["launches_per_step"]]
+            source = "HIP events on the launch stream, kernel launched back to back at the layer shape"
         if timed:
             dom = max(timed, key=lambda r: r["ms_per_step"])
-            traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same batch)
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_kernels_b32.json")
-            if os.path.exists(pmc_path):
-                pmc = json.load(open(pmc_path))
-                if pmc.get("batch") == args.batch and dom["kernel"] in pmc["kernels"]:
-                    traffic = pmc["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
+            # HBM bytes per launch: not measurable from inside the process -- taken from the newest committed
+            # rocprofv3 PMC digest (same kernel, same batch), and labelled so
+            traffic, traffic_source = None, None
+            pmc, pmc_path = latest_pmc_digest()
+            if pmc and pmc.get("batch") == args.batch and dom["kernel"] in pmc.get("kernels", {}):
+                traffic = pmc["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
+                traffic_source = f"{pmc_path} (committed rocprofv3 --pmc passes of this bench command; not measured in this run)"
             line["roofline"] = {
                 "kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac_of_f32_mfma_peak"],
-                "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "flop_per_launch": dom["flop"],
-                "measured": "HIP events on the launch stream around every launch of this kernel in the timed steps",
+                "traffic": traffic, "traffic_source": traffic_source,
+                "avg_launch_ms": dom["avg_ms"], "flop_per_launch": dom["flop"], "measured": source,
             }
             line["kernels_in_step"] = timed
-        if kernels and not timed:
-            dom = max(kernels[:4], key=lambda r: r["ms_per_step"])
-            traffic = None  # HBM bytes per launch from the committed PMC passes (same kernel, same batch)
-            pmc_path = os.path.join(ROOT, "profiles", "r01_pmc_kernels_b32.json")
-            if os.path.exists(pmc_path):
-                pmc = json.load(open(pmc_path))
-                if pmc.get("batch") == args.batch and dom["kernel"] in pmc["kernels"]:
-                    traffic = pmc["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
-            line["roofline"] = {
-                "kernel": dom["kernel"], "bound": "mfma", "achieved": dom["tflops"],
-                "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac_of_f32_mfma_peak"],
-                "traffic": traffic, "avg_launch_ms": dom["avg_ms"], "flop_per_launch": dom["flop"],
-            }
-        if shared:
-            line["variant_shared_generator_forward"] = shared
-        if x6:
-            line["variant_split_bf16_attention_forward"] = x6
+        line.update(variants)
         if kernels:
             line["kernels_microbench"] = kernels
         if cpu:

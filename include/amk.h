@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 110 /* 0.1.10: agent workspace arguments, layernorm / colsum entry points, codebook_dim 128 / 256 */
+#define AMK_VERSION 120 /* 0.2.0: kept attention scores (amk_attn_fwd_keep / amk_attn_bwd_kept), 256-key backward workgroups */
 
 enum {
   AMK_OK = 0,
@@ -73,6 +73,21 @@ int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float
                  int64_t o_sb, int64_t o_st, int64_t o_sh,
                  float scale, void* stream);
 
+/* The same forward, which also leaves the raw scores for the backward (training): scores must hold
+ * amk_attn_scores_bytes(B, H, I, J) bytes (4 bytes per (b, h, i, j), both sequence lengths padded to the
+ * kernels' tiles; 32x32 tiles, [b][h][key block][query block][key][query]).  The reference keeps the same
+ * tensor alive for autograd (models/softmax_attention.py:62, the einsum output); here it is written
+ * once and read once, by amk_attn_bwd_kept, which then runs four matrix products instead of five. */
+int64_t amk_attn_scores_bytes(int B, int H, int I, int J);
+int amk_attn_fwd_keep(const float* q, const float* k, const float* v, float* o, float* stats, float* scores,
+                      const uint8_t* key_mask, const uint8_t* causal_mask,
+                      int B, int H, int I, int J, int D,
+                      int64_t q_sb, int64_t q_st, int64_t q_sh,
+                      int64_t k_sb, int64_t k_st, int64_t k_sh,
+                      int64_t v_sb, int64_t v_st, int64_t v_sh,
+                      int64_t o_sb, int64_t o_st, int64_t o_sh,
+                      float scale, void* stream);
+
 /* The same forward with split-bf16 products: every f32 operand is split into three bf16 parts
  * (24 mantissa bits) and each product is the sum of six exact partial products accumulated in f32
  * (v_mfma_f32_32x32x16_bf16).  Same arguments, outputs, statistics and masks; the error against a
@@ -107,6 +122,10 @@ int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, fl
 #define AMK_ATTN_BWD_FUSED 8
 #define AMK_ATTN_BWD_ALL 7          /* delta + dK/dV + dQ: reproducible */
 #define AMK_ATTN_BWD_FAST 9         /* delta + fused */
+/* fused pass only: keys per workgroup (neither bit: 256 when J >= 256, else 128).  256 halves the
+ * number of atomic adds per dq element (J / 256 instead of J / 128). */
+#define AMK_ATTN_BWD_KEYS128 16
+#define AMK_ATTN_BWD_KEYS256 32
 int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  const float* stats, const float* d_o,
                  float* dq, float* dk, float* dv, float* delta_ws,
@@ -121,6 +140,24 @@ int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
                  int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
                  float scale, int stages, void* stream);
+/* amk_attn_bwd reading the scores amk_attn_fwd_keep left (same q, k, masks, scale): the fused pass skips
+ * its S = QK^T product; the results are those of amk_attn_bwd bit for bit (dq up to the atomics' order).
+ * `stages` must contain AMK_ATTN_BWD_FUSED; when the fused pass cannot run (causal mask, strided dq) the
+ * two recompute kernels run and the scores are not read. */
+int amk_attn_bwd_kept(const float* scores, const float* q, const float* k, const float* v, const float* o,
+                      const float* stats, const float* d_o,
+                      float* dq, float* dk, float* dv, float* delta_ws,
+                      const uint8_t* key_mask, const uint8_t* causal_mask,
+                      int B, int H, int I, int J, int D,
+                      int64_t q_sb, int64_t q_st, int64_t q_sh,
+                      int64_t k_sb, int64_t k_st, int64_t k_sh,
+                      int64_t v_sb, int64_t v_st, int64_t v_sh,
+                      int64_t o_sb, int64_t o_st, int64_t o_sh,
+                      int64_t do_sb, int64_t do_st, int64_t do_sh,
+                      int64_t dq_sb, int64_t dq_st, int64_t dq_sh,
+                      int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
+                      int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
+                      float scale, int stages, void* stream);
 
 /* --------------------------------------------------------------------------
  * VQ codebook nearest-neighbour lookup.
@@ -284,6 +321,31 @@ int amk_swiglu_bwd(const float* ab, const float* d_out, int64_t M, int H, float*
  * with the exact (erf) GELU of F.gelu; same layout and rules as the SwiGLU pair above. */
 int amk_geglu_fwd(const float* ab, int64_t M, int H, float* out, void* stream);
 int amk_geglu_bwd(const float* ab, const float* d_out, int64_t M, int H, float* d_ab, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Optimizer step over flat gradient buckets.
+ * Replaces, per phase of the train step, accelerator.clip_grad_norm_ + Adam.step + zero_grad
+ * (trainers/vitgqgan.py:67-68,159-163,185-189; trainers/vit.py:29-31,74-76 for AdamW):
+ *
+ *   amk_sumsq_partials   partials[w] (w < amk_opt_num_partials()) = sum of x^2 over the w-th fixed range
+ *   amk_adam_flat_step   norm = sqrt(sum of all `partials`), coef = min(1, max_norm / (norm + 1e-6))
+ *                        (max_norm <= 0: no clipping), then for every element of an ACTIVE parameter
+ *                          g *= coef; [Adam: g += wd * p | AdamW: p -= lr * wd * p]
+ *                          m += (1 - beta1) (g - m); v = beta2 v + (1 - beta2) g^2
+ *                          p -= tab.step_size * m / (sqrt(v) / tab.bc2_sqrt + eps)
+ *                        and grad is left zeroed (all parameters).  torch.optim.Adam / AdamW arithmetic.
+ * Buffers are flat fp32 arrays of n elements, n a multiple of 256; the i-th segment of 256 elements
+ * belongs to parameter seg_param[i]; param_tab is (P, 4) floats per step: {active (0 / 1),
+ * lr / (1 - beta1^t), sqrt(1 - beta2^t), unused} with t the parameter's own step count.
+ * Inactive parameters (no gradient this step) are left untouched, as optimizers skip .grad None.
+ * -------------------------------------------------------------------------- */
+int amk_opt_num_partials(void);
+int amk_sumsq_partials(const float* x, int64_t n, float* partials, void* stream);
+int amk_adam_flat_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                       const int32_t* seg_param, const float* param_tab,
+                       const float* partials, int n_partials,
+                       float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                       int decoupled, float* norm_out, void* stream);
 
 #ifdef __cplusplus
 }

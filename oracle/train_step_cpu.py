@@ -11,7 +11,10 @@ import torch.nn.functional as F
 from . import ref_cpu
 
 
-def _step(w, names, cfg, discr, g_opt, d_opt, img, adv_w=0.1, laplace_w=1.0, max_norm=1.0):
+def _step(w, names, cfg, discr, g_opt, d_opt, img, adv_w=0.1, laplace_w=1.0, max_norm=1.0, eta=None):
+    """One step of trainers/vitgqgan.py:139-189 (per_loss_weight 0).  `eta`: the gradient penalty's
+    interpolation weights (reference :116 draws them uniformly; the parity test passes the same ones to
+    both sides).  Returns the logged scalars (reference :201-204)."""
     params = [w[n] for n in names]
     # discriminator phase
     for p in params:
@@ -20,7 +23,8 @@ def _step(w, names, cfg, discr, g_opt, d_opt, img, adv_w=0.1, laplace_w=1.0, max
         p.requires_grad_(True)
     rec, _, _ = ref_cpu.vitvqgan_forward(img, w, cfg)
     fake, real = discr(rec), discr(img)
-    eta = torch.rand(img.shape[0], 1, 1, 1)
+    if eta is None:
+        eta = torch.rand(img.shape[0], 1, 1, 1)
     mixed = (eta * img + (1 - eta) * rec).detach().requires_grad_(True)
     pred = discr(mixed)
     (g,) = torch.autograd.grad(pred, mixed, torch.ones_like(pred), create_graph=True, retain_graph=True)
@@ -36,12 +40,14 @@ def _step(w, names, cfg, discr, g_opt, d_opt, img, adv_w=0.1, laplace_w=1.0, max
     for p in discr.parameters():
         p.requires_grad_(False)
     rec, cb_loss, _ = ref_cpu.vitvqgan_forward(img, w, cfg)
-    loss = cb_loss + adv_w * F.softplus(-discr(rec)).mean() + laplace_w * F.l1_loss(rec, img) + F.mse_loss(rec, img)
+    g_loss, l1, l2 = F.softplus(-discr(rec)).mean(), F.l1_loss(rec, img), F.mse_loss(rec, img)
+    loss = cb_loss + adv_w * g_loss + laplace_w * l1 + l2
     loss.backward()
     torch.nn.utils.clip_grad_norm_(params, max_norm)
     g_opt.step()
     g_opt.zero_grad()
-    return float(loss.detach())
+    return dict(d_loss=float(d_loss.detach()), g_loss=float(g_loss.detach()), l1=float(l1.detach()),
+                l2=float(l2.detach()), codebook_loss=float(cb_loss.detach()), loss=float(loss.detach()))
 
 
 def host_cores():

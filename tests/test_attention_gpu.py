@@ -14,17 +14,24 @@ pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
 
-@pytest.fixture(params=["fused", "deterministic", "fused-x6fwd"], autouse=True)
+@pytest.fixture(params=["fused", "fused-kept-128", "fused-recompute-128", "fused-recompute-256", "deterministic",
+                        "fused-x6fwd"], autouse=True)
 def backward_path(request):
-    """Every test runs with both backward paths of the attention core (amk_attn_bwd `stages`) and
-    with the split-bf16 forward (amk_attn_fwd_x6) in front of the fused backward."""
+    """Every test runs with every backward path of the attention core (amk_attn_bwd `stages`): the fused
+    pass reading the scores the forward kept (the default) or recomputing them, with 128 or 256 keys per
+    workgroup; the two reproducible recompute kernels; and the split-bf16 forward (amk_attn_fwd_x6) in
+    front of the fused backward."""
     from amk import ops
 
-    old = ops.DETERMINISTIC_ATTENTION_BACKWARD, ops.ATTENTION_FORWARD
+    old = (ops.DETERMINISTIC_ATTENTION_BACKWARD, ops.ATTENTION_FORWARD, ops.ATTENTION_KEEP_SCORES,
+           ops.ATTENTION_BACKWARD_KEYS)
     ops.DETERMINISTIC_ATTENTION_BACKWARD = request.param == "deterministic"
     ops.ATTENTION_FORWARD = "bf16x6" if request.param.endswith("x6fwd") else "f32"
+    ops.ATTENTION_KEEP_SCORES = "recompute" not in request.param
+    ops.ATTENTION_BACKWARD_KEYS = 128 if request.param.endswith("128") else (256 if request.param.endswith("256") else 0)
     yield request.param
-    ops.DETERMINISTIC_ATTENTION_BACKWARD, ops.ATTENTION_FORWARD = old
+    (ops.DETERMINISTIC_ATTENTION_BACKWARD, ops.ATTENTION_FORWARD, ops.ATTENTION_KEEP_SCORES,
+     ops.ATTENTION_BACKWARD_KEYS) = old
 
 
 def _core_case(device, B, H, I, J, key_mask=None, causal=None, seed=0, layout="bthd"):
@@ -206,3 +213,36 @@ def test_full_size_properties(device):
     # one (batch, head) slice against the oracle
     o_ref = ref_cpu.attention_core(q[3:4, 5:6].cpu(), k[3:4, 5:6].cpu(), v1[3:4, 5:6].cpu(), s)
     assert_close(a[3:4, 5:6], o_ref, TOL, "slice vs oracle")
+
+
+@pytest.mark.parametrize("B,H,I,J", [(2, 2, 200, 130), (1, 2, 1024, 1024), (2, 1, 33, 300)])
+def test_kept_scores_equal_recomputed_scores(device, backward_path, B, H, I, J):
+    """The scores amk_attn_fwd_keep leaves are bit for bit what the fused backward would recompute: dk and
+    dv (no atomics) must be IDENTICAL between amk_attn_bwd_kept and amk_attn_bwd, for both workgroup sizes;
+    dq may differ in the order of its atomic adds only."""
+    if backward_path != "fused":
+        pytest.skip("one pass is enough: the test drives every variant itself")
+    from amk import ops
+
+    D = 64
+    mk = lambda seed, T: seeded((B, T, H, D), seed).to(device).permute(0, 2, 1, 3)
+    q, k, v, d_o = mk(1, I), mk(2, J), mk(3, J), mk(4, I)
+    km = torch.ones(B, J, dtype=torch.uint8)
+    km[0, 5::7] = 0
+    km = km.to(device)
+    scale = D ** -0.5
+    q, k, v, o, stats, scores = ops._attn_forward(q, k, v, km, None, scale, keep_scores=True)
+    assert scores is not None
+    outs = {}
+    for keys in (16, 32):  # AMK_ATTN_BWD_KEYS128 / KEYS256
+        for kept in (False, True):
+            dq, dk, dv = (torch.full_like(t, float("nan")) for t in (q, k, v))
+            ops._attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, km, None, scale, stages=9 | keys,
+                               scores=scores if kept else None)
+            outs[(keys, kept)] = (dq, dk, dv)
+    ref = outs[(16, False)]
+    for key, (dq, dk, dv) in outs.items():
+        assert torch.equal(dk, outs[(key[0], False)][1]) and torch.equal(dv, outs[(key[0], False)][2]), key
+        assert_close(dq, ref[0], 2e-6, f"dq {key}")
+        assert_close(dk, ref[1], 2e-6, f"dk {key}")
+        assert_close(dv, ref[2], 2e-6, f"dv {key}")

@@ -96,10 +96,16 @@ def test_grad_reducer_bucket_layout():
     red.begin()
     net[:2](torch.randn(3, 8)).sum().backward()                   # the last layer gets no gradient
     red.finish()
-    assert float(params[-1].grad.abs().sum()) == 0.0 and float(params[0].grad.abs().sum()) > 0.0
+    # no gradient this step: .grad is detached (optimizers skip the parameter, as in the reference), zeros travel
+    assert params[-1].grad is None and float(red.buckets[0].views[0].abs().sum()) == 0.0
+    assert [id(p) for p in red.unused_parameters()] == [id(params[-1]), id(params[-2])]
+    assert float(params[0].grad.abs().sum()) > 0.0
     red.zero_grad()
     assert all(float(b.flat.abs().sum()) == 0.0 for b in red.buckets)
-    assert red.grads_nbytes() == sum(p.numel() for p in params) * 4
+    assert all(p.grad is not None for p in params)                # re-attached to the buckets
+    # every parameter starts on a 1-KiB boundary of its bucket (amk.optim.FlatAdam walks 256-element segments)
+    assert all(o % 256 == 0 for b in red.buckets for o in b.offsets)
+    assert red.grads_nbytes() == sum(-(-p.numel() // 256) * 256 for p in params) * 4
 
 
 def test_discriminator_conv_second_order_matches_nn_conv2d():
