@@ -290,6 +290,12 @@ def attention_fused_kv(q2, kv2, num_heads, dim_head, scale, key_mask=None, causa
 
 
 # ---------------------------------------------------------------------------- VQ lookup
+# vq_gather (indices_to_embeddings) takes indices from the caller: an index outside the codebook is never
+# dereferenced by the kernel, and with CHECK_INDICES the call raises IndexError like nn.Embedding does -- at
+# the price of one device-to-host read.  Set False (AMK_CHECK_INDICES=0) inside HIP-graph capture.
+CHECK_INDICES = os.environ.get("AMK_CHECK_INDICES", "1") == "1"
+
+
 def vq_nsplit(N, K):
     """Codebook slices per row block.  The sweep kernel keeps 4 workgroups per CU resident and hides
     its LDS latency behind the other workgroups' MFMAs, so it wants >= 16 workgroups per CU
@@ -297,7 +303,7 @@ def vq_nsplit(N, K):
     with slices no shorter than 1024 codes (at N = 8192 sixteen slices of 512 lose to eight of 1024)."""
     row_blocks = (N + 127) // 128
     nsplit = 1
-    while row_blocks * nsplit < 4096 and K % (64 * nsplit) == 0 and K // (2 * nsplit) >= 1024:
+    while row_blocks * nsplit < 4096 and K // (2 * nsplit) >= 1024:
         nsplit *= 2
     return nsplit
 
@@ -315,8 +321,9 @@ class _VQLookup(torch.autograd.Function):
         L = _lib.load()
         nsplit = vq_nsplit(N, K)
         f32 = dict(device=dev, dtype=torch.float32)
-        en = torch.empty((K, C), **f32)
-        ee = torch.empty((K,), **f32)
+        kp = L.amk_vq_padded_codes(K, nsplit)  # any K: the normalised copy is padded to whole tiles per slice
+        en = torch.empty((kp, C), **f32)
+        ee = torch.empty((kp,), **f32)
         pmin = torch.empty((N, nsplit), **f32)
         pidx = torch.empty((N, nsplit), device=dev, dtype=torch.int32)
         idx = torch.empty((N,), device=dev, dtype=torch.int64)
@@ -375,9 +382,12 @@ def vq_gather(indices, codebook):
     flat = indices.contiguous().view(-1).to(torch.int64)
     N = flat.shape[0]
     out = torch.empty((N, C), device=codebook.device, dtype=torch.float32)
+    bad = torch.zeros((1,), device=codebook.device, dtype=torch.int32)
     L = _lib.load()
-    rc = L.amk_vq_gather(_ptr(flat), _ptr(codebook.detach().contiguous()), N, K, C, _ptr(out), _stream())
+    rc = L.amk_vq_gather(_ptr(flat), _ptr(codebook.detach().contiguous()), N, K, C, _ptr(out), _ptr(bad), _stream())
     _lib.check(rc, "amk_vq_gather")
+    if CHECK_INDICES and int(bad.item()):  # one host read per call; nn.Embedding raises here too
+        raise IndexError(f"vq_gather: {int(bad.item())} of {N} indices are outside the codebook [0, {K})")
     return out.view(*indices.shape, C)
 
 

@@ -41,9 +41,10 @@ __device__ __forceinline__ float f4(const float4& v, int e) {
 
 // ---------------------------------------------------------------------------------------
 template <int C>
-__global__ __launch_bounds__(256) void vq_prep_codebook_kernel(const float* __restrict__ E, int K,
+__global__ __launch_bounds__(256) void vq_prep_codebook_kernel(const float* __restrict__ E, int K, int Kpad,
                                                                float* __restrict__ en, float* __restrict__ ee) {
-  // C/4 lanes per code row, one float4 each.
+  // C/4 lanes per code row, one float4 each.  Rows K .. Kpad-1 (K rounded up to whole 32-code tiles per
+  // slice) are padding: en = 0, ee = +inf, so their score <zn, en> - ee/2 = -inf is never the maximum.
   constexpr int LPR = C / 4;
   const int row = blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   const int c = (threadIdx.x % LPR) * 4;
@@ -60,6 +61,9 @@ __global__ __launch_bounds__(256) void vq_prep_codebook_kernel(const float* __re
   if (row < K) {
     st4(en + (int64_t)row * C + c, y);
     if (c == 0) ee[row] = s2;
+  } else if (row < Kpad) {
+    st4(en + (int64_t)row * C + c, make_float4(0.f, 0.f, 0.f, 0.f));
+    if (c == 0) ee[row] = INFINITY;
   }
 }
 
@@ -113,20 +117,25 @@ __global__ __launch_bounds__(256, (C <= 64 ? 2 : 1)) void vq_argmin_kernel(const
   const int kbeg = split * kper;
   const int ntile = (kper + CODES_LDS - 1) / CODES_LDS;
 
-  // staging: CODES_LDS*C floats per tile = (CODES_LDS*C/4) float4 over 256 threads
+  // staging: a tile is CODES_LDS*C CONTIGUOUS floats of the slice = (CODES_LDS*C/4) float4 over 256
+  // threads, fetched through a buffer descriptor that ends with the slice: rows past it read as zeros
+  // (hardware range check), so a tile costs NF4 loads and no compares, selects or 64-bit address math
+  // (every VALU instruction is paid against the f32 MFMA pipe).
   constexpr int NF4 = CODES_LDS * C / 4 / 256;
+  const __amdgpu_buffer_rsrc_t en_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(en + (int64_t)kbeg * C), 0, kper * C * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ee_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(ee + kbeg), 0, kper * 4, 0x00020000);
   float4 est[NF4];
   float eest = 0.f;
   auto prefetch = [&](int t) {
-    const int c0 = kbeg + t * CODES_LDS;
-    const int lim = kbeg + kper;
+    const int tile_off = t * CODES_LDS * C * 4;  // bytes, wave-uniform
 #pragma unroll
-    for (int ps = 0; ps < NF4; ++ps) {
-      const int f = tid + 256 * ps;
-      const int r = f / (C / 4), c4 = f % (C / 4);
-      est[ps] = (c0 + r < lim) ? ld4(en + (int64_t)(c0 + r) * C + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    if (tid < CODES_LDS) eest = (c0 + tid < lim) ? ee[c0 + tid] : INFINITY;
+    for (int ps = 0; ps < NF4; ++ps)
+      est[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(en_rsrc, (tid + 256 * ps) * 16, tile_off, 0));
+    // one ee per code; codes past the slice must score -inf: the range check returns 0 there, so the
+    // padding value is put in by the select below (one VALU instruction per tile)
+    const float e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ee_rsrc, (tid & (CODES_LDS - 1)) * 4, t * CODES_LDS * 4, 0));
+    eest = (t * CODES_LDS + (tid & (CODES_LDS - 1)) < kper) ? e : INFINITY;
   };
   auto commit = [&]() {
 #pragma unroll
@@ -282,7 +291,7 @@ template <int C>
 __global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ z, const float* __restrict__ E,
                                                      const float* __restrict__ zn, const float* __restrict__ zq,
                                                      const int64_t* __restrict__ idx, const float* __restrict__ g_out,
-                                                     const float* __restrict__ g_loss, float beta, int64_t N,
+                                                     const float* __restrict__ g_loss, float beta, int64_t N, int K,
                                                      float* __restrict__ dz, float* __restrict__ dE) {
   // one lane per element, C lanes per row: the codebook atomics of a wave then form
   // 64/C whole 4*C-byte row segments per instruction.
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ z
   const int c = threadIdx.x % C;
   const bool valid = row < N;
   const int64_t off = valid ? row * C + c : 0;
-  const int64_t code = valid ? idx[row] : 0;
+  const int64_t code = valid ? min(max(idx[row], (int64_t)0), (int64_t)K - 1) : 0;  // never outside the codebook
   const float zr = valid ? z[off] : 0.f;
   const float er = valid ? E[code * C + c] : 0.f;
   const float znv = valid ? zn[off] : 0.f;
@@ -326,14 +335,14 @@ template <int C>
 __global__ __launch_bounds__(256) void vq_bwd_wide_kernel(const float* __restrict__ z, const float* __restrict__ E,
                                                           const float* __restrict__ zn, const float* __restrict__ zq,
                                                           const int64_t* __restrict__ idx, const float* __restrict__ g_out,
-                                                          const float* __restrict__ g_loss, float beta, int64_t N,
+                                                          const float* __restrict__ g_loss, float beta, int64_t N, int K,
                                                           float* __restrict__ dz, float* __restrict__ dE) {
   constexpr int LPR = C / 4;
   const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   const int c = (threadIdx.x % LPR) * 4;
   const bool valid = row < N;
   const int64_t off = valid ? row * C + c : 0;
-  const int64_t code = valid ? idx[row] : 0;
+  const int64_t code = valid ? min(max(idx[row], (int64_t)0), (int64_t)K - 1) : 0;  // never outside the codebook
   const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 zr = valid ? ld4(z + off) : zero, er = valid ? ld4(E + code * C + c) : zero;
   const float4 znv = valid ? ld4(zn + off) : zero, zqv = valid ? ld4(zq + off) : zero;
@@ -376,12 +385,21 @@ __global__ __launch_bounds__(256) void vq_bwd_wide_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(256) void vq_gather_kernel(const int64_t* __restrict__ idx, const float* __restrict__ E,
-                                                        int64_t N, float* __restrict__ out) {
+                                                        int64_t N, int K, float* __restrict__ out, int32_t* __restrict__ bad) {
   constexpr int LPR = C / 4;
   const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   const int c = (threadIdx.x % LPR) * 4;
   float4 e = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (row < N) e = ld4(E + idx[row] * C + c);
+  if (row < N) {
+    // indices come from the caller: never read outside the codebook; out-of-range ones are counted
+    // (torch raises IndexError for them; the binding does the same from the count)
+    int64_t code = idx[row];
+    if (code < 0 || code >= K) {
+      if (bad && c == 0) atomicAdd(bad, 1);
+      code = code < 0 ? 0 : K - 1;
+    }
+    e = ld4(E + code * C + c);
+  }
   float ss = e.x * e.x + e.y * e.y + e.z * e.z + e.w * e.w;
 #pragma unroll
   for (int o = LPR / 2; o >= 1; o >>= 1) ss += __shfl_xor(ss, o, 64);
@@ -391,12 +409,12 @@ __global__ __launch_bounds__(256) void vq_gather_kernel(const int64_t* __restric
 
 // ---------------------------------------------------------------------------------------
 template <int C>
-int launch_fwd(const float* z, const float* E, int64_t N, int K, int nsplit, float* en, float* ee, float* pmin,
+int launch_fwd(const float* z, const float* E, int64_t N, int K, int Kpad, int nsplit, float* en, float* ee, float* pmin,
                int32_t* pidx, int64_t* idx, float* out, float* zq, float* zn, float* sqerr, hipStream_t st) {
   constexpr int LPR = C / 4;
-  hipLaunchKernelGGL(vq_prep_codebook_kernel<C>, dim3((K + 256 / LPR - 1) / (256 / LPR)), dim3(256), 0, st, E, K, en, ee);
+  hipLaunchKernelGGL(vq_prep_codebook_kernel<C>, dim3((Kpad + 256 / LPR - 1) / (256 / LPR)), dim3(256), 0, st, E, K, Kpad, en, ee);
   const int64_t nrb = (N + ROWS_WG - 1) / ROWS_WG;
-  hipLaunchKernelGGL(vq_argmin_kernel<C>, dim3((unsigned)(nrb * nsplit)), dim3(256), 0, st, z, en, ee, N, K, nsplit, zn,
+  hipLaunchKernelGGL(vq_argmin_kernel<C>, dim3((unsigned)(nrb * nsplit)), dim3(256), 0, st, z, en, ee, N, Kpad, nsplit, zn,
                      pmin, pidx);
   hipLaunchKernelGGL(vq_finalize_kernel<C>, dim3((unsigned)((N + FIN_ROWS - 1) / FIN_ROWS)), dim3(FIN_ROWS * LPR), 0, st,
                      E, en, ee, zn, pmin, pidx, N, nsplit, idx, out, zq, sqerr);
@@ -409,6 +427,13 @@ using namespace amk_vq;
 
 extern "C" int64_t amk_vq_num_partials(int64_t N) { return (N + FIN_ROWS - 1) / FIN_ROWS; }
 
+// rows of the en / ee workspaces: K rounded up to whole 32-code tiles in each of the nsplit slices
+extern "C" int amk_vq_padded_codes(int K, int nsplit) {
+  if (K <= 0 || nsplit <= 0) return 0;
+  const int q = 32 * nsplit;
+  return (K + q - 1) / q * q;
+}
+
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 extern "C" int amk_vq_lookup_fwd(const float* z, const float* codebook, int64_t N, int K, int C, int nsplit,
@@ -419,15 +444,16 @@ extern "C" int amk_vq_lookup_fwd(const float* z, const float* codebook, int64_t 
                 "amk_vq_lookup_fwd: null pointer");
   AMK_CHECK_ARG(N > 0 && K > 0 && nsplit > 0, "amk_vq_lookup_fwd: non-positive size N=%lld K=%d nsplit=%d", (long long)N, K, nsplit);
   AMK_CHECK_SUPPORTED(C == 32 || C == 64 || C == 128 || C == 256, "amk_vq_lookup_fwd: codebook_dim %d not supported (32, 64, 128, 256)", C);
-  AMK_CHECK_SUPPORTED(K % (32 * nsplit) == 0, "amk_vq_lookup_fwd: K=%d must be a multiple of 32*nsplit=%d", K, 32 * nsplit);
+  const int Kpad = amk_vq_padded_codes(K, nsplit);  // en_ws / ee_ws hold Kpad rows
+  AMK_CHECK_SUPPORTED((int64_t)Kpad * C * 4 < (1ll << 31), "amk_vq_lookup_fwd: codebook too large");
   AMK_CHECK_ARG(a16(z) && a16(codebook) && a16(en_ws) && a16(out) && a16(zq) && a16(zn), "amk_vq_lookup_fwd: pointers must be 16-byte aligned");
   const int64_t nwg = ((N + ROWS_WG - 1) / ROWS_WG) * nsplit;
   AMK_CHECK_SUPPORTED(nwg < (1ll << 31) && (N + FIN_ROWS - 1) / FIN_ROWS < (1ll << 31), "amk_vq_lookup_fwd: grid too large");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (C == 32) launch_fwd<32>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
-  else if (C == 64) launch_fwd<64>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
-  else if (C == 128) launch_fwd<128>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
-  else launch_fwd<256>(z, codebook, N, K, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  if (C == 32) launch_fwd<32>(z, codebook, N, K, Kpad, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  else if (C == 64) launch_fwd<64>(z, codebook, N, K, Kpad, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  else if (C == 128) launch_fwd<128>(z, codebook, N, K, Kpad, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
+  else launch_fwd<256>(z, codebook, N, K, Kpad, nsplit, en_ws, ee_ws, pmin_ws, pidx_ws, idx, out, zq, zn, sqerr_partial, st);
   AMK_CHECK_LAUNCH("amk_vq_lookup_fwd");
   return AMK_OK;
 }
@@ -448,18 +474,19 @@ extern "C" int amk_vq_lookup_bwd(const float* z, const float* codebook, const fl
   AMK_CHECK_SUPPORTED(nb < (1ll << 31), "amk_vq_lookup_bwd: grid too large");
   AMK_CHECK_ARG(C <= 64 || (a16(z) && a16(codebook) && a16(zn) && a16(zq) && a16(g_out) && a16(dz)), "amk_vq_lookup_bwd: pointers must be 16-byte aligned");
   if (C == 32)
-    hipLaunchKernelGGL(vq_bwd_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
+    hipLaunchKernelGGL(vq_bwd_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook);
   else if (C == 64)
-    hipLaunchKernelGGL(vq_bwd_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
+    hipLaunchKernelGGL(vq_bwd_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook);
   else if (C == 128)
-    hipLaunchKernelGGL(vq_bwd_wide_kernel<128>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
+    hipLaunchKernelGGL(vq_bwd_wide_kernel<128>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook);
   else
-    hipLaunchKernelGGL(vq_bwd_wide_kernel<256>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, dz, dcodebook);
+    hipLaunchKernelGGL(vq_bwd_wide_kernel<256>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook);
   AMK_CHECK_LAUNCH("amk_vq_lookup_bwd");
   return AMK_OK;
 }
 
-extern "C" int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, int C, float* out, void* stream) {
+extern "C" int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, int C, float* out,
+                             int32_t* bad_count, void* stream) {
   AMK_CHECK_ARG(idx && codebook && out, "amk_vq_gather: null pointer");
   AMK_CHECK_ARG(N > 0 && K > 0, "amk_vq_gather: non-positive size");
   AMK_CHECK_SUPPORTED(C == 32 || C == 64 || C == 128 || C == 256, "amk_vq_gather: codebook_dim %d not supported (32, 64, 128, 256)", C);
@@ -467,10 +494,10 @@ extern "C" int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t 
   const int rpb = 256 / (C / 4);
   const int64_t nb = (N + rpb - 1) / rpb;
   AMK_CHECK_SUPPORTED(nb < (1ll << 31), "amk_vq_gather: grid too large");
-  if (C == 32) hipLaunchKernelGGL(vq_gather_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
-  else if (C == 64) hipLaunchKernelGGL(vq_gather_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
-  else if (C == 128) hipLaunchKernelGGL(vq_gather_kernel<128>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
-  else hipLaunchKernelGGL(vq_gather_kernel<256>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, out);
+  if (C == 32) hipLaunchKernelGGL(vq_gather_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, K, out, bad_count);
+  else if (C == 64) hipLaunchKernelGGL(vq_gather_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, K, out, bad_count);
+  else if (C == 128) hipLaunchKernelGGL(vq_gather_kernel<128>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, K, out, bad_count);
+  else hipLaunchKernelGGL(vq_gather_kernel<256>, dim3((unsigned)nb), dim3(256), 0, st, idx, codebook, N, K, out, bad_count);
   AMK_CHECK_LAUNCH("amk_vq_gather");
   return AMK_OK;
 }

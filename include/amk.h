@@ -172,12 +172,15 @@ int amk_attn_bwd_kept(const float* scores, const float* q, const float* k, const
  *   sqerr_partial[w] = partial sums of (zq - zn)^2 ; the caller forms
  *        loss = (1 + beta) * sum(sqerr_partial) / (N*C)
  *
- * C must be 32 or 64.  nsplit >= 1 splits the codebook over workgroups; K must
- * be a multiple of 32*nsplit.  Workspaces: en_ws K*C floats, ee_ws K floats,
- * pmin_ws N*nsplit floats, pidx_ws N*nsplit int32.  sqerr_partial holds
+ * C must be 32, 64, 128 or 256; K is any positive size (the reference takes any codebook_size,
+ * models/vitvqgan.py:141).  nsplit >= 1 splits the codebook over workgroups; internally the
+ * normalised codebook is padded to Kp = amk_vq_padded_codes(K, nsplit) rows (whole 32-code tiles
+ * per slice; the padding scores -inf and is never chosen).  Workspaces: en_ws Kp*C floats,
+ * ee_ws Kp floats, pmin_ws N*nsplit floats, pidx_ws N*nsplit int32.  sqerr_partial holds
  * amk_vq_num_partials(N) floats.  The distance matrix is never written to HBM.
  * -------------------------------------------------------------------------- */
 int64_t amk_vq_num_partials(int64_t N);
+int amk_vq_padded_codes(int K, int nsplit);
 int amk_vq_lookup_fwd(const float* z, const float* codebook, int64_t N, int K, int C, int nsplit,
                       float* en_ws, float* ee_ws, float* pmin_ws, int32_t* pidx_ws,
                       int64_t* idx, float* out, float* zq, float* zn, float* sqerr_partial,
@@ -193,9 +196,13 @@ int amk_vq_lookup_bwd(const float* z, const float* codebook, const float* zn, co
                       const int64_t* idx, const float* g_out, const float* g_loss, float beta,
                       int64_t N, int K, int C, float* dz, float* dcodebook, void* stream);
 
-/* Codebook.indices_to_embeddings (models/vitvqgan.py:173-176): out[n] = l2norm(E[idx[n]]). */
+/* Codebook.indices_to_embeddings (models/vitvqgan.py:173-176): out[n] = l2norm(E[idx[n]]).
+ * The indices are the caller's: one outside [0, K) is never dereferenced (it reads row 0 or K-1) and
+ * is counted in *bad_count (device int32, zeroed by the caller; NULL = do not count) -- the reference
+ * raises IndexError there (nn.Embedding), and so does the Python binding from the count.
+ * amk_vq_lookup_bwd clamps its (forward-produced) indices the same way. */
 int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, int C,
-                  float* out, void* stream);
+                  float* out, int32_t* bad_count, void* stream);
 
 /* --------------------------------------------------------------------------
  * Top-k expert routing and grouped expert GEMMs.

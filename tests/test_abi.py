@@ -28,7 +28,7 @@ def test_argument_errors_are_reported_not_crashed():
     null = ctypes.c_void_p(0)
     rc = L.amk_attn_fwd(null, null, null, null, null, null, null, 1, 1, 1, 1, 64, *([0] * 12), 1.0, null)
     assert rc == -1 and b"null" in L.amk_last_error()
-    rc = L.amk_vq_gather(null, null, 1, 1, 32, null, null)
+    rc = L.amk_vq_gather(null, null, 1, 1, 32, null, null, null)
     assert rc == -1
     with pytest.raises(RuntimeError, match="amk_vq_gather"):
         amk_lib.check(rc, "amk_vq_gather")

@@ -67,7 +67,10 @@ def test_codebook_config3_golden_indices(device):
 
 
 @pytest.mark.parametrize("N,K,C", [(1, 32, 32), (100, 64, 32), (129, 512, 64), (1000, 2048, 32), (4096, 8192, 32),
-                                   (300, 256, 128), (513, 1024, 256), (33, 32, 256)])
+                                   (300, 256, 128), (513, 1024, 256), (33, 32, 256),
+                                   # codebook sizes that are not whole tiles (the reference takes any K)
+                                   (257, 1000, 32), (64, 1, 32), (200, 5, 64), (4096, 8191, 32), (130, 3000, 32),
+                                   (77, 100, 128), (40, 33, 256)])
 def test_lookup_vs_oracle(device, N, K, C):
     from amk import ops
 
@@ -89,6 +92,22 @@ def test_lookup_vs_oracle(device, N, K, C):
     gz, gE = torch.autograd.grad((zq * cot.to(device)).sum() + 2.0 * loss, [zd, Ed])
     assert_close(gz, gz_r, TOL, "grad z")
     assert_close(gE, gE_r, TOL, "grad codebook")
+
+
+def test_indices_to_embeddings_rejects_out_of_range_indices(device):
+    """nn.Embedding raises IndexError for an index outside the codebook (models/vitvqgan.py:173-176);
+    the kernel never dereferences such an index and the binding raises from its count."""
+    from amk import ops
+
+    K, C = 100, 32
+    E = seeded((K, C), 9).to(device)
+    good = torch.tensor([[0, 5, 99]], device=device)
+    want = torch.nn.functional.normalize(E[good.view(-1)], dim=-1).view(1, 3, C)
+    assert_close(ops.vq_gather(good, E), want, 1e-6, "gather")
+    for bad in ([[0, 100, 3]], [[-1, 2, 3]], [[1 << 40, 2, 3]]):
+        with pytest.raises(IndexError, match="outside the codebook"):
+            ops.vq_gather(torch.tensor(bad, device=device), E)
+    torch.cuda.synchronize()   # no device fault behind the exception
 
 
 def test_exact_ties_take_first_index(device):

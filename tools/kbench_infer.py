@@ -15,7 +15,10 @@ import torch  # noqa: E402
 
 import bench  # noqa: E402
 from amk import tuning  # noqa: E402
+from amk import ops  # noqa: E402
 from amk.graphs import GraphedStep  # noqa: E402
+
+ops.CHECK_INDICES = False  # the index check of decode_indices reads the device: not inside a captured graph
 from amk.models import ViTVQGAN  # noqa: E402
 
 
