@@ -134,10 +134,11 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=False):
     o = _new_bthd(B, H, I, D, q)
     stats = torch.empty((B, H, I, 2), device=q.device, dtype=torch.float32)
     L = _lib.load()
-    x6 = ATTENTION_FORWARD == "bf16x6"
+    x6 = ATTENTION_FORWARD == "bf16x6" and D == 64  # head dims 32 / 128 run the plain f32 kernels
     ws = torch.empty((L.amk_attn_fwd_x6_ws_bytes(B, H, J),), device=q.device, dtype=torch.uint8) if x6 else None
     scores = None
-    if keep_scores and not x6 and causal_mask is None and ATTENTION_KEEP_SCORES and not DETERMINISTIC_ATTENTION_BACKWARD:
+    if (keep_scores and D == 64 and not x6 and causal_mask is None and ATTENTION_KEEP_SCORES
+            and not DETERMINISTIC_ATTENTION_BACKWARD):
         nbytes = L.amk_attn_scores_bytes(B, H, I, J)
         if nbytes <= ATTENTION_KEEP_SCORES_MAX_BYTES:
             scores = torch.empty((nbytes // 4,), device=q.device, dtype=torch.float32)

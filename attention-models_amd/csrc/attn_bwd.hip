@@ -392,7 +392,8 @@ static int attn_bwd_impl(const float* scores, const float* q, const float* k, co
                             float scale, int stages, void* stream) {
   AMK_CHECK_ARG(q && k && v && o && stats && d_o && dq && dk && dv && delta_ws, "amk_attn_bwd: null tensor pointer");
   AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_bwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
-  AMK_CHECK_SUPPORTED(Dh == D, "amk_attn_bwd: head dim %d not supported (built for %d)", Dh, D);
+  AMK_CHECK_SUPPORTED(Dh == D || attn_gen_supported(Dh), "amk_attn_bwd: head dim %d not supported (32, 64, 128)", Dh);
+  AMK_CHECK_SUPPORTED(Dh == D || !scores, "amk_attn_bwd_kept: kept scores exist for head dim %d only", D);
   BwdParams p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.stats = stats; p.d_o = d_o;
   p.dq = dq; p.dk = dk; p.dv = dv; p.delta = delta_ws;
@@ -418,6 +419,11 @@ static int attn_bwd_impl(const float* scores, const float* q, const float* k, co
                           ((int64_t)I + TILE) * q_st * 4 < (1ll << 31) && ((int64_t)I + TILE) * do_st * 4 < (1ll << 31),
                       "amk_attn_bwd: one (batch, head) slab must span < 2 GiB");
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (Dh != D) {
+    launch_attn_bwd_gen(p, Dh, stages, st);
+    AMK_CHECK_LAUNCH("amk_attn_bwd");
+    return AMK_OK;
+  }
   if (stages & AMK_ATTN_BWD_DELTA)
     hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((nrow + 15) / 16)), dim3(256), 0, st, p);
   if (stages & AMK_ATTN_BWD_FUSED) {

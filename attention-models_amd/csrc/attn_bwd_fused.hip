@@ -271,6 +271,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dSl[acc_row(r, hf) * DS_STRIDE + 32 * wave + ln] = dp[r];
 
+    // the next tile's scores (consumed after the next tile's dP product: three MFMA phases from here;
+    // the last iteration re-reads its own tile, unused)
+    if (KEPT) {
+      load_scores(tile_of(min(t + 1, ntile - 1)));
+      __builtin_amdgcn_sched_barrier(0);  // issued HERE: the compiler otherwise sinks them below the MFMAs
+    }
+
     // ---- dV^T += dO^T P ; dK^T += (q*scale*log2e)^T dS   (2 x 32 MFMAs)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -281,9 +288,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
       dk0 = mfma32(qc[0], dp[r], dk0);
       dk1 = mfma32(qc[32], dp[r], dk1);
     }
-    // the score registers are free: fetch the next tile's (consumed after the next tile's dP product;
-    // the last iteration re-reads its own tile, unused)
-    if (KEPT) load_scores(tile_of(min(t + 1, ntile - 1)));
     __syncthreads();  // every wave's dS columns are in LDS; the q / dO / stats tiles are dead
     commit();         // (the last iteration commits a tile nobody reads)
     {

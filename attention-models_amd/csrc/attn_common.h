@@ -124,4 +124,9 @@ void launch_attn_fwd_x6(const FwdParams& p, int64_t nwg, hipStream_t st);
 // attn_bwd_fused.hip: one-pass backward (dQ by atomics); false = not applicable, nothing launched.
 bool launch_attn_bwd_fused(const BwdParams& p, int keys_per_wg, hipStream_t st);
 
+// attn_generic.hip: head dims 32 and 128 (forward + the two recompute kernels of the backward)
+bool attn_gen_supported(int Dh);
+void launch_attn_fwd_gen(const FwdParams& p, int Dh, int64_t nwg, hipStream_t st);
+void launch_attn_bwd_gen(const BwdParams& p, int Dh, int stages, hipStream_t st);
+
 }  // namespace amk_attn

@@ -279,7 +279,8 @@ static int attn_fwd_impl(void* x6_ws, bool x6, float* scores, const float* q, co
                          float scale, void* stream) {
   AMK_CHECK_ARG(q && k && v && o && stats, "amk_attn_fwd: null tensor pointer");
   AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_fwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
-  AMK_CHECK_SUPPORTED(Dh == D, "amk_attn_fwd: head dim %d not supported (built for %d)", Dh, D);
+  AMK_CHECK_SUPPORTED(Dh == D || attn_gen_supported(Dh), "amk_attn_fwd: head dim %d not supported (32, 64, 128)", Dh);
+  AMK_CHECK_SUPPORTED(Dh == D || (!x6 && !scores), "amk_attn_fwd: the split-bf16 and score-keeping forwards are built for head dim %d", D);
   FwdParams p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.stats = stats;
   p.key_mask = key_mask; p.causal_mask = causal_mask;
@@ -300,7 +301,9 @@ static int attn_fwd_impl(void* x6_ws, bool x6, float* scores, const float* q, co
   AMK_CHECK_SUPPORTED(((int64_t)J + TILE) * k_st * 4 < (1ll << 31) && ((int64_t)J + TILE) * v_st * 4 < (1ll << 31),
                       "amk_attn_fwd: one (batch, head) K/V slab must span < 2 GiB");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (x6)
+  if (Dh != D)
+    launch_attn_fwd_gen(p, Dh, nwg, st);
+  else if (x6)
     launch_attn_fwd_x6(p, nwg, st);
   else if (causal_mask && scores)
     hipLaunchKernelGGL((attn_fwd_kernel<true, false, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);

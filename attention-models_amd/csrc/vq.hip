@@ -85,8 +85,10 @@ __global__ __launch_bounds__(256, (C <= 64 ? 2 : 1)) void vq_argmin_kernel(const
   const int ln = lane & 31, hf = lane >> 5;
 
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int split = wg % nsplit;       // consecutive ids share the z rows, walk the slices
-  const int64_t rb = wg / nsplit;
+  // (readfirstlane: the division runs on the vector unit; without it the loads through the slice's buffer
+  // descriptor below are wrapped in waterfall loops)
+  const int split = __builtin_amdgcn_readfirstlane(wg % nsplit);  // consecutive ids share the z rows, walk the slices
+  const int64_t rb = __builtin_amdgcn_readfirstlane(wg / nsplit);
   const int64_t row = rb * ROWS_WG + wave * 32 + ln;
   const bool rvalid = row < N;
 
@@ -127,24 +129,28 @@ __global__ __launch_bounds__(256, (C <= 64 ? 2 : 1)) void vq_argmin_kernel(const
   const __amdgpu_buffer_rsrc_t ee_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(ee + kbeg), 0, kper * 4, 0x00020000);
   float4 est[NF4];
   float eest = 0.f;
+  bool ee_ok = false;
   auto prefetch = [&](int t) {
     const int tile_off = t * CODES_LDS * C * 4;  // bytes, wave-uniform
 #pragma unroll
     for (int ps = 0; ps < NF4; ++ps)
       est[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(en_rsrc, (tid + 256 * ps) * 16, tile_off, 0));
-    // one ee per code; codes past the slice must score -inf: the range check returns 0 there, so the
-    // padding value is put in by the select below (one VALU instruction per tile)
-    const float e = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ee_rsrc, (tid & (CODES_LDS - 1)) * 4, t * CODES_LDS * 4, 0));
-    eest = (t * CODES_LDS + (tid & (CODES_LDS - 1)) < kper) ? e : INFINITY;
+    // one ee per code (the range check returns 0 past the slice; commit() puts the padding value in)
+    eest = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ee_rsrc, (tid & (CODES_LDS - 1)) * 4, t * CODES_LDS * 4, 0));
+    ee_ok = t * CODES_LDS + (tid & (CODES_LDS - 1)) < kper;
   };
   auto commit = [&]() {
+    // nothing that consumes the loads may be scheduled up to them (it would wait out the memory latency
+    // in front of a tile's MFMAs): the loads were issued a tile ago
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int ps = 0; ps < NF4; ++ps) {
       const int f = tid + 256 * ps;
       const int r = f / (C / 4), c4 = f % (C / 4);
       st4(&Es[r * LS + 4 * c4], est[ps]);
     }
-    if (tid < CODES_LDS) EEs[tid] = -0.5f * eest;   // padding: ee = +inf -> score -inf, never chosen
+    // codes past the slice: ee = +inf -> score -inf, never chosen
+    if (tid < CODES_LDS) EEs[tid] = ee_ok ? -0.5f * eest : -INFINITY;
   };
 
   // vq.hip is compiled with -fno-honor-nans -mno-amdgpu-ieee (Makefile): fmaxf is then a bare

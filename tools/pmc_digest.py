@@ -20,16 +20,28 @@ from collections import defaultdict
 
 
 def short(name):
-    m = re.search(r"(\w+_kernel)", name)
-    return m.group(1) if m else name
+    """Kernel name without namespace / arguments; the template variants bench.py reports separately keep
+    their bench.py names: attn_fwd_kernel<.., .., true> = attn_fwd_keep_kernel (writes the scores),
+    attn_bwd_fused_kernel<NW, true> = attn_bwd_fused_kernel(kept scores)."""
+    m = re.search(r"(\w+_kernel)(<[^>]*>)?", name)
+    if not m:
+        return name
+    base, targs = m.group(1), (m.group(2) or "").replace(" ", "")
+    if base == "attn_bwd_fused_kernel" and targs.endswith(",true>"):
+        return base + "(kept scores)"
+    if base == "attn_fwd_kernel" and targs.endswith(",true>"):
+        return "attn_fwd_keep_kernel"
+    return base
 
 
-def fold(path):
+def fold(path, only=None):
     acc = defaultdict(lambda: defaultdict(list))
     dur = defaultdict(list)
     seen = set()
     for r in csv.DictReader(open(path)):
         if "amk_" not in r["Kernel_Name"]:
+            continue
+        if only and not any(o in r["Kernel_Name"] for o in only):
             continue
         k = short(r["Kernel_Name"])
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
