@@ -433,16 +433,19 @@ class _RoutedLinear(torch.autograd.Function):
         dev = x2.device
         if x2.shape != (P // x_div, Kd) or U % outer:
             raise RuntimeError(f"routed linear shapes disagree: x {tuple(x2.shape)} U {U} k {k} x_div {x_div} W {tuple(W.shape)}")
-        r = moe_route(logits2.detach(), k)
+        with _timed(f"moe_route U{U} E{E} k{k}"):
+            r = moe_route(logits2.detach(), k)
         L = _lib.load()
         Y = torch.empty((P, N), device=dev, dtype=torch.float32)
-        rc = L.amk_grouped_gemm_nt(_ptr(x2), Kd, x_div, _ptr(W), _ptr(bias), _ptr(r["offsets"]), _ptr(r["perm"]),
-                                   P, E, N, Kd, _ptr(Y), _stream())
+        with _timed(f"grouped_nt P{P} N{N} K{Kd}"):
+            rc = L.amk_grouped_gemm_nt(_ptr(x2), Kd, x_div, _ptr(W), _ptr(bias), _ptr(r["offsets"]), _ptr(r["perm"]),
+                                       P, E, N, Kd, _ptr(Y), _stream())
         _lib.check(rc, "amk_grouped_gemm_nt")
         G = U // outer
         out = torch.empty((G, N), device=dev, dtype=torch.float32)
-        rc = L.amk_moe_combine(_ptr(Y), _ptr(r["ids"]), _ptr(r["gate"]) if weighted else _NULL, G, outer, k, N,
-                               _ptr(out), _stream())
+        with _timed(f"moe_combine G{G} N{N} x{outer * k}"):
+            rc = L.amk_moe_combine(_ptr(Y), _ptr(r["ids"]), _ptr(r["gate"]) if weighted else _NULL, G, outer, k, N,
+                                   _ptr(out), _stream())
         _lib.check(rc, "amk_moe_combine")
         ctx.save_for_backward(x2, W, Y, r["ids"], r["gate"], r["offsets"], r["perm"])
         ctx.cfg = (k, x_div, weighted, outer, E, bias is not None)
@@ -467,16 +470,18 @@ class _RoutedLinear(torch.autograd.Function):
             rc = L.amk_moe_gate_grad(_ptr(d_out), _ptr(Y), _ptr(ids), _ptr(gate), P, k, E, N, g_div, _ptr(dlogits), _stream())
             _lib.check(rc, "amk_moe_gate_grad")
         dxp = torch.empty((P, Kd), device=dev, dtype=torch.float32)
-        rc = L.amk_grouped_gemm_nn(_ptr(d_out), N, g_div, _ptr(W), scale, _ptr(offsets), _ptr(perm), P, E, N, Kd,
-                                   _ptr(dxp), _stream())
+        with _timed(f"grouped_nn P{P} N{N} K{Kd}"):
+            rc = L.amk_grouped_gemm_nn(_ptr(d_out), N, g_div, _ptr(W), scale, _ptr(offsets), _ptr(perm), P, E, N, Kd,
+                                       _ptr(dxp), _stream())
         _lib.check(rc, "amk_grouped_gemm_nn")
         dx = torch.empty_like(x2)
         rc = L.amk_moe_combine(_ptr(dxp), _ptr(ids), _NULL, x2.shape[0], x_div // k, k, Kd, _ptr(dx), _stream())
         _lib.check(rc, "amk_moe_combine")
         dW = torch.empty_like(W)
         db = torch.empty((E, N), device=dev, dtype=torch.float32) if has_bias else None
-        rc = L.amk_grouped_gemm_wgrad(_ptr(d_out), N, g_div, _ptr(x2), Kd, x_div, scale, _ptr(offsets), _ptr(perm),
-                                      P, E, N, Kd, _ptr(dW), _ptr(db), _stream())
+        with _timed(f"grouped_wgrad P{P} N{N} K{Kd}"):
+            rc = L.amk_grouped_gemm_wgrad(_ptr(d_out), N, g_div, _ptr(x2), Kd, x_div, scale, _ptr(offsets), _ptr(perm),
+                                          P, E, N, Kd, _ptr(dW), _ptr(db), _stream())
         _lib.check(rc, "amk_grouped_gemm_wgrad")
         return dx, dlogits, dW, db, None, None, None, None
 

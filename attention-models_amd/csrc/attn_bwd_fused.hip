@@ -126,7 +126,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
   auto load_scores = [&](int qt) {
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-      sk[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sc_rsrc, sc_voff + 32 * g, qt * 4096, 2));
+      sk[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sc_rsrc, sc_voff + qt * 4096 + 32 * g, 0, 2));
   };
 
   constexpr int QNP = RowStagerT<TQ, NT>::NP;  // 16-B pieces per thread of a 32-row tile (2 or 1)

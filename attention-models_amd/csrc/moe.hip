@@ -23,6 +23,7 @@
 // store, per-lane bias), operands through LDS with row stride 36 / 68 floats (conflict-free
 // ds_read_b128 row reads, ds_read_b32 column reads).
 #include "amk_common.h"
+#include <stdlib.h>
 
 namespace amk_moe {
 
@@ -44,23 +45,53 @@ constexpr int MAX_K = 8;
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict__ logits, int64_t U, int E, int k,
                                                          int64_t* __restrict__ ids, float* __restrict__ gate) {
-  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (u >= U) return;
-  const float* lg = logits + u * E;
-  int chosen[MAX_K];
-#pragma unroll 1
-  for (int s = 0; s < k; ++s) {
-    float best = -INFINITY;
-    int bi = -1;
-    for (int e = 0; e < E; ++e) {
-      bool taken = false;
-      for (int j = 0; j < s; ++j) taken |= (chosen[j] == e);
-      const float v = lg[e];
-      if (!taken && (bi < 0 || v > best)) { best = v; bi = e; }
+  // A block takes 256 consecutive units = 256*E CONTIGUOUS logits; they are staged through LDS in
+  // chunks of 32 experts by coalesced loads (consecutive threads read consecutive floats of a unit's
+  // row; a thread reading its own row directly would touch 64 rows per instruction), then every thread
+  // merges its unit's 32 values into a sorted top-k list: descending value, lowest index on ties --
+  // the order torch.topk gives on distinct values.
+  constexpr int EC = 32;
+  __shared__ float tile[256 * (EC + 1)];
+  const int tid = threadIdx.x;
+  const int64_t u0 = (int64_t)blockIdx.x * 256;
+  const int64_t u = u0 + tid;
+  float bv[MAX_K];
+  int bi[MAX_K];
+#pragma unroll
+  for (int s = 0; s < MAX_K; ++s) { bv[s] = -INFINITY; bi[s] = -1; }
+  const int nu = (int)min((int64_t)256, U - u0);
+  for (int e0 = 0; e0 < E; e0 += EC) {
+    const int ne = min(EC, E - e0);
+    __syncthreads();
+    for (int f = tid; f < nu * ne; f += 256) {  // f -> (unit f / ne, expert f % ne): ne consecutive floats per row
+      const int r = f / ne, c = f % ne;
+      tile[r * (EC + 1) + c] = logits[(u0 + r) * E + e0 + c];
     }
-    chosen[s] = bi;
-    ids[u * k + s] = bi;
-    gate[u * k + s] = 1.f / (1.f + expf(-best));
+    __syncthreads();
+    if (u < U) {
+      for (int c = 0; c < ne; ++c) {
+        const float v = tile[tid * (EC + 1) + c];
+        // insert (v, e0 + c) behind every entry with value >= v (equal values: the earlier index stays first)
+        if (bi[k - 1] < 0 || v > bv[k - 1]) {
+          int pos = k - 1;
+#pragma unroll
+          for (int s = MAX_K - 2; s >= 0; --s) {
+            if (s < k - 1 && (bi[s] < 0 || v > bv[s])) { bv[s + 1] = bv[s]; bi[s + 1] = bi[s]; pos = s; }
+          }
+#pragma unroll
+          for (int s = 0; s < MAX_K; ++s)
+            if (s == pos) { bv[s] = v; bi[s] = e0 + c; }
+        }
+      }
+    }
+  }
+  if (u < U) {
+#pragma unroll
+    for (int s = 0; s < MAX_K; ++s)
+      if (s < k) {
+        ids[u * k + s] = bi[s];
+        gate[u * k + s] = 1.f / (1.f + expf(-bv[s]));
+      }
   }
 }
 
@@ -157,6 +188,7 @@ struct GemmParams {
   int E, N, Kd;
   int a_div, b_div;
   int64_t lda, ldb;
+  int64_t a_bytes;       // size of the A buffer (wide kernels: buffer-descriptor range)
 };
 
 // Locate (expert, m-tile) for this workgroup: tiles are dealt expert by expert.
@@ -187,6 +219,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
   const int n0 = blockIdx.y * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
+  const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
   if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
   __syncthreads();
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
@@ -225,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
     commit();
     __syncthreads();
     if (k0 + 32 < g.Kd) prefetch(k0 + 32);
+    if (!rows_here) continue;  // a tail tile with at most 32 pairs: this wave's row half is empty
     const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
     const float* wr = &Ws[(32 * NB * wn + ln) * LS + 16 * hf];
 #pragma unroll
@@ -254,6 +288,92 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
   }
 }
 
+// The same product for the wide shapes (N >= 128, Kd a multiple of 64): tile 64 pairs x 128 outputs x 64
+// deep -- four times the MFMAs per barrier pair and per staged byte of grouped_nt_kernel<1> -- every wave
+// 32 pairs x 64 outputs (two accumulators sharing the A fragment).  Operands are staged through buffer
+// descriptors (pairs beyond the tile and rows beyond N read as zeros: no compares or selects) and the
+// tile loop has no branch around a vector-memory instruction, so every wait is a counted one.
+__global__ __launch_bounds__(256, 2) void grouped_nt_wide_kernel(GemmParams g) {
+  constexpr int BK = 64, LS = BK + 4, BN = 128;
+  __shared__ __attribute__((aligned(16))) float smem[(64 + BN) * LS];
+  __shared__ int prow[64];
+  float* As = smem;
+  float* Ws = smem + 64 * LS;
+  int e, m0, cnt;
+  if (!find_tile(g.offsets, g.E, blockIdx.x, e, m0, cnt)) return;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
+  if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
+  __syncthreads();
+  // staging: 16 threads per row (16 B each): A rows sr + 16 j (j < 4), W rows sr + 16 j (j < 8)
+  const int sr = tid >> 4, sc = (tid & 15) * 4;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
+  const float* We = g.W + (int64_t)e * g.N * g.Kd;
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, (int)((int64_t)g.N * g.Kd * 4), 0x00020000);
+  int aoff[4], woff[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int pp = prow[sr + 16 * j];
+    aoff[j] = pp >= 0 ? (int)(((int64_t)(pp / g.a_div) * g.lda + sc) * 4) : 0x7fffff00;  // past the buffer: zeros
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) woff[j] = (int)(((int64_t)(n0 + sr + 16 * j) * g.Kd + sc) * 4);  // rows >= N: past the buffer
+  float4 ast[4], wst[8];
+  auto prefetch = [&](int k0) {
+#pragma unroll
+    // (the k offset goes into the vector offset: that is the part the hardware range check covers)
+    for (int j = 0; j < 4; ++j) ast[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff[j] + k0 * 4, 0, 0));
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff[j] + k0 * 4, 0, 0));
+  };
+  auto commit = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) st4(&As[(sr + 16 * j) * LS + sc], ast[j]);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) st4(&Ws[(sr + 16 * j) * LS + sc], wst[j]);
+  };
+  f32x16 acc0 = zero16(), acc1 = zero16();
+  prefetch(0);
+  const int nk = g.Kd / BK;
+  for (int kt = 0; kt < nk; ++kt) {
+    __syncthreads();
+    commit();
+    __syncthreads();
+    prefetch(min(kt + 1, nk - 1) * BK);  // unconditional (the last step re-reads its own tile, unused)
+    if (!rows_here) continue;            // a tail tile with at most 32 pairs: this wave's row half is empty
+    const float* ar = &As[(32 * wm + ln) * LS + 32 * hf];
+    const float* wr = &Ws[(64 * wn + ln) * LS + 32 * hf];
+#pragma unroll
+    for (int s4 = 0; s4 < 8; ++s4) {
+      const float4 a = ld4(ar + 4 * s4);
+      const float4 b0 = ld4(wr + 4 * s4);
+      const float4 b1 = ld4(wr + 32 * LS + 4 * s4);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        acc0 = mfma32(f4(a, x), f4(b0, x), acc0);
+        acc1 = mfma32(f4(a, x), f4(b1, x), acc1);
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const f32x16& acc = j ? acc1 : acc0;
+    const int n = n0 + 64 * wn + 32 * j + ln;
+    if (n < g.N) {
+      const float bv = g.bias ? g.bias[(int64_t)e * g.N + n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int p = prow[32 * wm + acc_row(r, hf)];
+        if (p >= 0) g.Y[(int64_t)p * g.N + n] = acc[r] + bv;
+      }
+    }
+  }
+}
+
 // Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk]              tile: 64 pairs x 64*NB outputs
 template <int NB>
 __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
@@ -267,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
   const int c0 = blockIdx.y * BC;  // output (kk) tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
+  const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
   if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
   __syncthreads();
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
@@ -306,6 +427,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
     commit();
     __syncthreads();
     if (nb + 32 < g.N) prefetch(nb + 32);
+    if (!rows_here) continue;  // a tail tile with at most 32 pairs: this wave's row half is empty
     const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
     const float* wc_ = &Ws[(16 * hf) * WS + 32 * NB * wn + ln];
 #pragma unroll
@@ -529,7 +651,11 @@ extern "C" int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const
   g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
   const unsigned mt = (unsigned)((P + 63) / 64 + E);
   // measured at the ViTMoE layer shape (P 8320, N = Kd = 1024, E 32): NB 1 0.207 ms, NB 2 0.240 ms
-  hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt, (N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  g.a_bytes = ((P - 1) / a_div * lda + Kd) * 4;   // rows 0 .. (P-1)/a_div of A
+  if (N >= 128 && Kd % 64 == 0 && g.a_bytes < (1ll << 31) && (int64_t)N * Kd * 4 < (1ll << 31) && !getenv("AMK_MOE_NARROW"))
+    hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3(mt, (N + 127) / 128), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  else
+    hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt, (N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), g);
   AMK_CHECK_LAUNCH("amk_grouped_gemm_nt");
   return AMK_OK;
 }

@@ -131,12 +131,12 @@ __global__ __launch_bounds__(256, (C <= 64 ? 2 : 1)) void vq_argmin_kernel(const
   float eest = 0.f;
   bool ee_ok = false;
   auto prefetch = [&](int t) {
-    const int tile_off = t * CODES_LDS * C * 4;  // bytes, wave-uniform
+    const int tile_off = t * CODES_LDS * C * 4;  // bytes; added to the VECTOR offset, the part the range check covers
 #pragma unroll
     for (int ps = 0; ps < NF4; ++ps)
-      est[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(en_rsrc, (tid + 256 * ps) * 16, tile_off, 0));
+      est[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(en_rsrc, (tid + 256 * ps) * 16 + tile_off, 0, 0));
     // one ee per code (the range check returns 0 past the slice; commit() puts the padding value in)
-    eest = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ee_rsrc, (tid & (CODES_LDS - 1)) * 4, t * CODES_LDS * 4, 0));
+    eest = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ee_rsrc, (tid & (CODES_LDS - 1)) * 4 + t * CODES_LDS * 4, 0, 0));
     ee_ok = t * CODES_LDS + (tid & (CODES_LDS - 1)) < kper;
   };
   auto commit = [&]() {

@@ -132,6 +132,55 @@ def kernel_rooflines(B, dev, iters):
     return out
 
 
+def vitmoe_block(dev, batch=64, steps=3):
+    """Secondary, informational: BASELINE.json configs[3] (ViTMoE dim 1024, patch 32, depth 6, 32 experts top-2,
+    SwitchHead h 8) forward + backward at batch 64, with HIP events around every routed-expert launch.
+    Grouped expert GEMMs are credited 2*P*N*K FLOP (P routed pairs), against the f32 MFMA peak."""
+    import re
+
+    from amk import ops as amk_ops
+    from amk.models import ViTMoE
+
+    torch.manual_seed(0)
+    vm = ViTMoE(dim=1024, image_size=256, patch_size=32, n_heads=8, d_head=64, depth=6, n_experts=32, sel_experts=2,
+                dropout=0.0, num_classes=1000).to(dev)
+    g = torch.Generator().manual_seed(4321)
+    imgs = torch.randn(batch, 3, 256, 256, generator=g).to(dev)
+    labels = torch.randint(0, 1000, (batch,), generator=g).to(dev)
+
+    def step():
+        vm.zero_grad(set_to_none=True)
+        torch.nn.functional.cross_entropy(vm(imgs), labels).backward()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    amk_ops.KERNEL_EVENTS = {}
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ev = amk_ops.kernel_event_summary(amk_ops.KERNEL_EVENTS)
+    amk_ops.KERNEL_EVENTS = None
+    rows = []
+    for name, (n, ms) in sorted(ev.items()):
+        r = dict(kernel=name, launches_per_step=n / steps, avg_ms=ms, ms_per_step=ms * n / steps)
+        m = re.match(r"grouped_\w+ P(\d+) N(\d+) K(\d+)", name)
+        if m:
+            fl = 2.0 * int(m.group(1)) * int(m.group(2)) * int(m.group(3))
+            r.update(flop=fl, tflops=fl / (ms * 1e-3) / 1e12, frac_of_f32_mfma_peak=fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS)
+        rows.append(r)
+    del vm
+    torch.cuda.empty_cache()
+    return {"workload": "BASELINE.json configs[3]: ViTMoE dim=1024 patch=32 depth=6 n_experts=32 top-2 + SwitchHead h=8, "
+                        f"forward + cross-entropy + backward, batch {batch}, f32",
+            "ms_per_step": dt * 1e3, "images_per_s": batch / dt, "kernels": rows}
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: start the N rank processes from here.  The parent
     never touches HIP (no torch.cuda call), passes its own flags through, relays rank 0's JSON line and
@@ -282,6 +331,10 @@ def main():
     if rank == 0 and not args.no_kernels:
         kernels = kernel_rooflines(args.batch, dev, args.kernel_iters)
         note("kernel rooflines done")
+    vitmoe = None
+    if rank == 0 and world == 1 and not args.no_kernels and not args.no_variants:
+        vitmoe = vitmoe_block(dev)
+        note("ViTMoE block done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import train_step_cpu
@@ -353,6 +406,8 @@ def main():
         line.update(variants)
         if kernels:
             line["kernels_microbench"] = kernels
+        if vitmoe:
+            line["kernels_vitmoe"] = vitmoe
         if cpu:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)

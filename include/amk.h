@@ -62,7 +62,9 @@ const char* amk_last_error(void);
  * the (B,T,h*D) projection outputs are consumed in place (st = h*D, sh = D) as
  * well as (B,h,T,D) tensors (sh = T*D, st = D).  k and v likewise with J rows.
  * key_mask: uint8 (B,J) contiguous or NULL; causal_mask: uint8 (I,J) contiguous
- * or NULL.  stats: (B,H,I,2) contiguous.  D must be 64.
+ * or NULL.  stats: (B,H,I,2) contiguous.  D is 32, 64 or 128 (64: the tuned kernels, the split-bf16
+ * forward, kept scores and the one-pass backward; 32 / 128: the generic forward and the two
+ * reproducible backward kernels of csrc/attn_generic.hip).
  * -------------------------------------------------------------------------- */
 int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float* stats,
                  const uint8_t* key_mask, const uint8_t* causal_mask,

@@ -43,6 +43,6 @@ def test_integration_md_stub(device):
     assert_close(o, ref_cpu.attention_core(q, k, v, D ** -0.5, km), 2e-5, "stub output vs oracle")
     assert tuple(o.permute(0, 2, 1, 3).reshape(B, I, H * D).shape) == (B, I, H * D)   # no copy needed for W_o
     # error path: unsupported head dim comes back as a code + message, not an exception across the ABI
-    q32 = torch.zeros(1, 1, 4, 32, device=device)
+    q48 = torch.zeros(1, 1, 4, 48, device=device)   # head dims 32, 64 and 128 are built
     with pytest.raises(RuntimeError):
-        attn_core(q32, q32, q32, 1.0)
+        attn_core(q48, q48, q48, 1.0)
