@@ -3,6 +3,7 @@ classes on the hot path and their scaffolding."""
 from .attention import AgentAttention, SoftmaxAttention, SwitchHeadAttention
 from .model_factory import build_model
 from .moe import MoELayer
+from .maskgit import BiDirectionalTransformer, MaskGitTransformer
 from .muse import MUSE, BidirectionalDecoder
 from .vit import ViT
 from .vit_moe import ViTMoE
@@ -10,4 +11,4 @@ from .vitvqgan import Codebook, ViTVQGAN
 from . import vqgan  # conv-VQGAN codebook (models/vqgan.py:138-182): vqgan.Codebook
 
 __all__ = ["SoftmaxAttention", "AgentAttention", "SwitchHeadAttention", "MoELayer", "Codebook", "ViTVQGAN",
-           "ViT", "ViTMoE", "MUSE", "BidirectionalDecoder", "build_model"]
+           "ViT", "ViTMoE", "MUSE", "BidirectionalDecoder", "MaskGitTransformer", "BiDirectionalTransformer", "build_model"]

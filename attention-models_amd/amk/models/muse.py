@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .transformer import Decoder, LayerNorm
 
 
@@ -62,8 +63,10 @@ class BidirectionalDecoder(nn.Module):
 
 
 class MUSE(nn.Module):
-    def __init__(self, dim, vq, text_dim=768, n_heads=8, d_head=64, depth=6, mult=4, embeds_drop_prob=0.9, dropout=0.0):
+    def __init__(self, dim, vq, text_dim=768, n_heads=8, d_head=64, depth=6, mult=4, embeds_drop_prob=0.9, dropout=0.0,
+                 fused_sampling=True):
         super().__init__()
+        self.fused_sampling = fused_sampling  # generate(): the per-step sampling chain as one kernel
         self.project_embeds = nn.Linear(text_dim, dim)  # text_encoder.project_embeds in the reference
         self.vq = vq
         codebook_size = vq.codebook.codebook_size
@@ -114,11 +117,17 @@ class MUSE(nn.Module):
             ids = ids.masked_fill(mask, self.mask_token_id)
             logits = self.decoder(ids, context=ctx)                     # two decoder passes per step:
             null_logits = self.decoder(ids, context=null_ctx)           # conditional + unconditional
-            scaled = null_logits + 3 * (logits - null_logits)           # classifier-free guidance, scale 3
-            probs = F.softmax(scaled, dim=-1)
             temperature = 1 * (steps_until_x0 / timesteps)
-            pred = F.gumbel_softmax(filter_logits(scaled, p=0.9), tau=temperature, hard=False, dim=-1).argmax(dim=-1)
-            ids[mask] = pred[mask]
-            scores = probs.gather(2, pred.unsqueeze(-1)).squeeze(-1)
+            if self.fused_sampling:
+                # CFG (scale 3) + softmax + top-(1-p) filter + Gumbel-argmax + score gather + masked write:
+                # one pass over the logits (csrc/sample.hip) instead of the op chain below
+                scores = ops.sample_step(logits, ids, mask=mask, null_logits=null_logits, cfg_scale=3.0,
+                                         tau=temperature, p=0.9)
+            else:
+                scaled = null_logits + 3 * (logits - null_logits)       # classifier-free guidance, scale 3
+                probs = F.softmax(scaled, dim=-1)
+                pred = F.gumbel_softmax(filter_logits(scaled, p=0.9), tau=temperature, hard=False, dim=-1).argmax(dim=-1)
+                ids[mask] = pred[mask]
+                scores = probs.gather(2, pred.unsqueeze(-1)).squeeze(-1)
             mask = torch.zeros_like(mask)
         return self.vq.decode_indices(ids)

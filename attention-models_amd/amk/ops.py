@@ -392,6 +392,40 @@ def vq_gather(indices, codebook):
     return out.view(*indices.shape, C)
 
 
+# ---------------------------------------------------------------------------- masked-token sampling step
+_SAMPLE_CALLS = 0
+
+
+def sample_step(logits, ids, mask=None, null_logits=None, cfg_scale=3.0, tau=1.0, p=0.9, gumbel=None, seed=None,
+                unmasked_score=None):
+    """One step of the parallel decode on (B, T, V) logits, in one pass (csrc/sample.hip): classifier-free
+    guidance, softmax, top-(1-p) filter, Gumbel-argmax at temperature tau, chosen probability.
+    ids (B, T) int64 is updated IN PLACE where mask (B, T) bool is True (everywhere without a mask);
+    returns scores (B, T).  gumbel: explicit noise (B, T, V) -- else drawn in-kernel (Philox; seeded from
+    torch's generator so that torch.manual_seed reproduces a run)."""
+    import math
+
+    global _SAMPLE_CALLS
+    _require_device(logits, null_logits, gumbel)
+    B, T, V = logits.shape
+    logits = logits.contiguous()
+    null_logits = null_logits.contiguous() if null_logits is not None else None
+    gumbel = gumbel.contiguous() if gumbel is not None else None
+    if ids.dtype != torch.int64 or not ids.is_contiguous():
+        raise RuntimeError("sample_step: ids must be a contiguous int64 tensor (updated in place)")
+    m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
+    scores = torch.empty((B, T), device=logits.device, dtype=torch.float32)
+    if seed is None:
+        seed = int(torch.initial_seed()) & ((1 << 63) - 1)
+    _SAMPLE_CALLS += 1
+    L = _lib.load()
+    rc = L.amk_sample_step(_ptr(logits), _ptr(null_logits), float(cfg_scale), _ptr(gumbel), seed, _SAMPLE_CALLS, float(tau),
+                           B * T, V, math.ceil((1 - p) * V), _ptr(m8), -1.0 if unmasked_score is None else float(unmasked_score),
+                           _ptr(ids), _ptr(scores), _stream())
+    _lib.check(rc, "amk_sample_step")
+    return scores
+
+
 # ---------------------------------------------------------------------------- routed experts
 def _i32(n, dev):
     return torch.empty((n,), device=dev, dtype=torch.int32)

@@ -469,28 +469,45 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_kernel(GemmParams g) {
   const int sr = tid >> 4, sc = (tid & 15) * 4;  // G: rows sr, sr+16 (pairs); cols sc
   constexpr int TPR = BC / 4, RPP = 256 / TPR;
   const int xr = tid / TPR, xc = (tid % TPR) * 4;  // X: rows xr + RPP*j
+  // Per step the 32 pairs' source rows and scales come from a small LDS table that 32 threads fill ONE STEP
+  // AHEAD (perm lookup, two integer divisions by run-time divisors, the scale): done per staged row by every
+  // thread, that bookkeeping was 9.7 VALU instructions per MFMA (PMC) -- every one paid against the f32 MFMA pipe.
+  __shared__ int tab_a[2][32], tab_x[2][32];
+  __shared__ float tab_s[2][32];
+  auto fill_table = [&](int step) {  // rows of pairs [32 step, 32 step + 32) of this expert; -1 = past the end
+    if (tid < 32) {
+      const int i = 32 * step + tid;
+      int ra = -1, rx = -1;
+      float sv = 0.f;
+      if (i < cnt) {
+        const int p = g.perm[beg + i];
+        ra = p / g.a_div;
+        rx = p / g.b_div;
+        sv = g.scale ? g.scale[p] : 1.f;
+      }
+      tab_a[step & 1][tid] = ra; tab_x[step & 1][tid] = rx; tab_s[step & 1][tid] = sv;
+    }
+  };
   float4 gst[2], xst[32 / RPP];
-  auto prefetch = [&](int m) {
+  const bool g_in = n0 + sc < g.N, x_in = c0 + xc < g.Kd;
+  auto prefetch = [&](int step) {
+    const int b = step & 1;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       gst[j] = zero4();
-      const int i = m + sr + 16 * j;
-      if (i < cnt && n0 + sc < g.N) {
-        const int p = g.perm[beg + i];
-        const float s = g.scale ? g.scale[p] : 1.f;
-        float4 t = ld4(g.A + (int64_t)(p / g.a_div) * g.lda + n0 + sc);
-        t.x *= s; t.y *= s; t.z *= s; t.w *= s;
+      const int ra = tab_a[b][sr + 16 * j];
+      if (ra >= 0 && g_in) {
+        const float sv = tab_s[b][sr + 16 * j];
+        float4 t = ld4(g.A + (int64_t)ra * g.lda + n0 + sc);
+        t.x *= sv; t.y *= sv; t.z *= sv; t.w *= sv;
         gst[j] = t;
       }
     }
 #pragma unroll
     for (int j = 0; j < 32 / RPP; ++j) {
       xst[j] = zero4();
-      const int i = m + xr + RPP * j;
-      if (i < cnt && c0 + xc < g.Kd) {
-        const int p = g.perm[beg + i];
-        xst[j] = ld4(g.B2 + (int64_t)(p / g.b_div) * g.ldb + c0 + xc);
-      }
+      const int rx = tab_x[b][xr + RPP * j];
+      if (rx >= 0 && x_in) xst[j] = ld4(g.B2 + (int64_t)rx * g.ldb + c0 + xc);
     }
   };
   auto commit = [&]() {
@@ -503,12 +520,17 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_kernel(GemmParams g) {
 #pragma unroll
   for (int j = 0; j < NB; ++j) acc[j] = zero16();
   float bsum = 0.f;
-  if (cnt > 0) prefetch(0);
-  for (int m = 0; m < cnt; m += 32) {
-    __syncthreads();
+  const int nstep = (cnt + 31) / 32;
+  fill_table(0);
+  __syncthreads();
+  if (nstep > 0) prefetch(0);
+  fill_table(1);
+  for (int st = 0; st < nstep; ++st) {
+    __syncthreads();  // tile st consumed by every wave; table st + 1 complete
     commit();
     __syncthreads();
-    if (m + 32 < cnt) prefetch(m + 32);
+    if (st + 1 < nstep) prefetch(st + 1);
+    fill_table(st + 2);  // into the buffer prefetch(st) read before the barriers above
     const float* gc = &Gs[(16 * hf) * GS + 32 * wm + ln];
     const float* xc_ = &Xs[(16 * hf) * XS + 32 * NB * wn + ln];
 #pragma unroll

@@ -356,6 +356,24 @@ int amk_adam_flat_step(float* param, float* grad, float* exp_avg, float* exp_avg
                        float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                        int decoupled, float* norm_out, void* stream);
 
+/* --------------------------------------------------------------------------
+ * One step of the masked-token parallel decode.
+ * Replaces, per step of MUSE.generate / MaskGitTransformer.generate (models/muse.py:211-236,
+ * models/maskgit.py:255-272), the chain CFG combine -> softmax -> filter_logits (top-k, scatter) ->
+ * gumbel_softmax(tau).argmax -> probs.gather -> masked writes over the (R, V) logits:
+ *   s      = null + cfg_scale * (logits - null)       (null_logits NULL: s = logits)
+ *   pred   = argmax over the `keep` largest s of (s + g)    (tau > 0; tau == 0 gives 0, as the reference's
+ *            division by zero does -- every Gumbel-softmax entry is NaN and argmax returns 0)
+ *   ids[r] = pred where mask[r] != 0 (mask NULL: every row)
+ *   scores[r] = softmax(s)[pred]; rows with mask[r] == 0 get `unmasked_score` when it is >= 0
+ * g: `gumbel` (R, V) when given, else -log(-log u) with u from Philox4x32-10 keyed by (seed, offset, row, j/4)
+ * -- torch's distribution, not its stream.  R rows of V logits (V % 4 == 0, V <= 36864), contiguous.
+ * -------------------------------------------------------------------------- */
+int amk_sample_step(const float* logits, const float* null_logits, float cfg_scale,
+                    const float* gumbel, uint64_t seed, uint64_t offset, float tau,
+                    int64_t R, int V, int keep, const uint8_t* mask, float unmasked_score,
+                    int64_t* ids, float* scores, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

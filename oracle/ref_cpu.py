@@ -335,3 +335,41 @@ def bidirectional_decoder(ids, context, w, n_heads, d_head, depth, context_mask=
         x = _geglu_ffn(_gamma_ln(x, lw, "norm3"), _sub(lw, "feed_forward")) + x
     x = _gamma_ln(x, w, "final_norm")
     return x @ w["linear.weight"].t()
+
+
+# ------------------------------------------------------------------ masked-token decoder (MaskGit)
+def maskgit_transformer(ids, w, n_heads, d_head, depth):
+    """BiDirectionalTransformer.forward (models/maskgit.py:80-91) over transformer.Encoder
+    (models/transformer.py:46-76): embedding + positions -> LN -> depth x (self-attention, GEGLU FFN; pre-LN,
+    residual) -> LN -> logits.  The reference file itself cannot be imported here (it imports cv2), so this
+    composition is restated from its text; its parts are the ones the other fixtures pin."""
+    x = w["input_proj.weight"][ids] + w["pos_enc"]
+    x = _gamma_ln(x, w, "init_norm")
+    for i in range(depth):
+        lw = _sub(w, f"decoder.layers.{i}")
+        x = softmax_attention(_gamma_ln(x, lw, "norm1"), _sub(lw, "self_attn"), n_heads, d_head) + x
+        x = _geglu_ffn(_gamma_ln(x, lw, "norm2"), _sub(lw, "feed_forward")) + x
+    x = _gamma_ln(x, w, "final_norm")
+    return x @ w["linear.weight"].t()
+
+
+def sampling_step(logits, ids, mask, gumbel, tau, null_logits=None, cfg_scale=3.0, p=0.9, unmasked_score=None):
+    """One step of the parallel decode as the reference writes it (models/muse.py:211-236,
+    models/maskgit.py:255-272), with the Gumbel noise given: CFG combine, softmax, filter_logits (top
+    ceil((1-p) V) logits, -inf elsewhere), argmax of softmax((filtered + g) / tau), probability gather,
+    masked id update.  Returns (new ids, scores)."""
+    import math
+
+    s = logits if null_logits is None else null_logits + cfg_scale * (logits - null_logits)
+    probs = torch.softmax(s, dim=-1)
+    k = math.ceil((1 - p) * s.shape[-1])
+    val, ind = s.topk(k, dim=-1)
+    filtered = torch.full_like(s, float("-inf")).scatter_(2, ind, val)
+    y = torch.softmax((filtered + gumbel) / tau, dim=-1)   # tau = 0: all NaN, argmax 0 (the reference's last step)
+    pred = y.argmax(dim=-1)
+    ids = ids.clone()
+    ids[mask] = pred[mask]
+    scores = probs.gather(2, pred.unsqueeze(-1)).squeeze(-1)
+    if unmasked_score is not None:
+        scores = scores.masked_fill(~mask, unmasked_score)
+    return ids, scores

@@ -62,3 +62,69 @@ def test_grad_reducer_on_rccl(device):
             assert torch.allclose(p.grad, 2 * w, rtol=1e-5, atol=1e-6)
     finally:
         dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# Two ranks on the GPU branch of GradReducer (side stream, ready events, stream join, FlatAdam on the
+# reduced buckets).  RCCL refuses two ranks on one device, and the test box has one GPU, so the two
+# processes share cuda:0 and talk over gloo -- the same rehearsal bench.py offers
+# (AMK_REHEARSE_SHARED_GPU=1); everything but the transport is the code the 8-GPU run executes.
+def _two_rank_worker(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "attention-models_amd"))
+    from amk.dp import GradReducer
+    from amk.models import SoftmaxAttention
+    from amk.optim import FlatAdam
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(50 + rank)  # different init per rank: the broadcast must fix it
+        net = nn.Sequential(SoftmaxAttention(128, 2, 64), nn.Linear(128, 16)).to(dev)
+        red = GradReducer(net.parameters(), bucket_bytes=64 << 10)
+        assert red.on_gpu and not red.alone and len(red.buckets) > 1
+        opt = FlatAdam(red, lr=1e-2)
+        red.broadcast_parameters()
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(4, 40, 128, generator=g)[2 * rank:2 * rank + 2].to(dev)
+        y = torch.randn(4, 40, 16, generator=g)[2 * rank:2 * rank + 2].to(dev)
+        red.begin(sync=True)
+        ((net(x) - y) ** 2).mean().backward()
+        red.finish()
+        grads = [p.grad.detach().cpu().clone() for p in net.parameters()]
+        order = list(red.launch_order)
+        opt.step(max_norm=1.0)
+        torch.cuda.synchronize()
+        torch.save(dict(grads=grads, order=order, params=[p.detach().cpu().clone() for p in net.parameters()]),
+                   os.path.join(out_dir, f"gpu_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_share_the_gpu_over_gloo(device, tmp_path):
+    import torch.multiprocessing as mp
+
+    from amk.models import SoftmaxAttention
+
+    mp.spawn(_two_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "gpu_rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "gpu_rank1.pt", weights_only=True)
+    assert r0["order"] == r1["order"] == sorted(r0["order"])          # buckets leave in index order on both ranks
+    # single-process reference from rank 0's initial weights: mean over the two half batches
+    torch.manual_seed(50)
+    net = nn.Sequential(SoftmaxAttention(128, 2, 64), nn.Linear(128, 16)).to(device)
+    g = torch.Generator().manual_seed(9)
+    x, y = torch.randn(4, 40, 128, generator=g).to(device), torch.randn(4, 40, 16, generator=g).to(device)
+    loss = sum(((net(x[i:i + 2]) - y[i:i + 2]) ** 2).mean() for i in (0, 2)) / 2
+    loss.backward()
+    for a, b, p in zip(r0["grads"], r1["grads"], net.parameters()):
+        assert torch.equal(a, b)                                       # both ranks hold the same averaged gradient
+        assert torch.allclose(a, p.grad.cpu(), rtol=2e-5, atol=1e-6)
+    for a, b in zip(r0["params"], r1["params"]):
+        assert torch.equal(a, b)                                       # and take the same optimizer step
