@@ -28,8 +28,8 @@ class SoftmaxAttention(nn.Module):
         self.dim_head = dim_head
         inner = num_heads * dim_head
         # Sequential containers only to keep the reference's "q.0.weight"/"kv.0.weight" keys.
-        self.q = nn.Sequential(nn.Linear(dim, inner, bias=False))
-        self.kv = nn.Sequential(nn.Linear(dim, 2 * inner, bias=False))
+        self.q = nn.Sequential(Linear(dim, inner, bias=False))
+        self.kv = nn.Sequential(Linear(dim, 2 * inner, bias=False))
         self.W_o = Linear(inner, dim)
         self.dropout_p = float(dropout)
         self.scale = dim_head ** -0.5

@@ -8,9 +8,9 @@ from .. import ops
 
 class Linear(nn.Linear):
     def forward(self, x):
-        if self.bias is None or not x.is_cuda:
+        if not x.is_cuda:
             return F.linear(x, self.weight, self.bias)
-        return ops.linear(x, self.weight, self.bias)
+        return ops.linear(x, self.weight, self.bias)   # library GEMM + amk_colsum, or the split-bf16 GEMM (ops.GEMM_MODE)
 
 
 class LayerNorm(nn.LayerNorm):

@@ -748,5 +748,68 @@ class _BiasLinear(torch.autograd.Function):
         return dx, dw, db
 
 
-def linear(x, weight, bias):
+# Dense GEMMs of the nn.Linear layers: "f32" = the vendor library's exact-f32 kernels (rocBLAS / hipBLASLt, chosen
+# by TunableOp; 0.79 of the f32 MFMA peak) -- the parity mode and the headline; "bf16x6" = csrc/gemm_x6.hip for the
+# forward and the input gradient (split-bf16 products: f32-level error, bound = bf16 MFMA peak / 6); the weight
+# gradient stays with the library.
+GEMM_MODE = os.environ.get("AMK_GEMM", "f32")
+
+
+def gemm_x6_nt(a2, b2, bias=None):
+    """a2 (M, K) @ b2 (N, K)^T (+ bias): F.linear on 2-D operands through amk_gemm_x6_nt."""
+    _require_device(a2, b2, bias)
+    if a2.stride(1) != 1:
+        a2 = a2.contiguous()
+    if b2.stride(1) != 1:
+        b2 = b2.contiguous()
+    M, K = a2.shape
+    N = b2.shape[0]
+    c = torch.empty((M, N), device=a2.device, dtype=torch.float32)
+    L = _lib.load()
+    with _timed(f"gemm_x6_nt M{M} N{N} K{K}"):
+        rc = L.amk_gemm_x6_nt(_ptr(a2), a2.stride(0), _ptr(b2), b2.stride(0), _ptr(bias), _ptr(c), N, M, N, K, _stream())
+    _lib.check(rc, "amk_gemm_x6_nt")
+    return c
+
+
+def _x6_ok(x, weight):
+    K = weight.shape[1]
+    return K % 4 == 0 and x.numel() > 0 and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
+
+
+class _LinearX6(torch.autograd.Function):
+    """F.linear with the forward and the input gradient on the split-bf16 GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        _require_device(x, weight, bias)
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, weight)
+        ctx.x_shape = x.shape
+        ctx.has_bias = bias is not None
+        return gemm_x6_nt(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, weight = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            N = weight.shape[0]
+            if N % 4 == 0:
+                dx = gemm_x6_nt(dy2, weight.t().contiguous()).view(ctx.x_shape)   # dY W = dY (W^T)^T
+            else:
+                dx = dy2.mm(weight).view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            dw = dy2.t().mm(x2)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = colsum(dy2)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    if GEMM_MODE == "bf16x6" and _x6_ok(x, weight):
+        return _LinearX6.apply(x, weight, bias)
+    if bias is None:
+        return torch.nn.functional.linear(x, weight)
     return _BiasLinear.apply(x, weight, bias)
