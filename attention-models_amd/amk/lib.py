@@ -52,7 +52,9 @@ SIGNATURES = {
     "amk_opt_num_partials": (_I, []),
     "amk_sumsq_partials": (_I, [_P, _L, _P, _P]),
     "amk_adam_flat_step": (_I, [_P] * 4 + [_L, _P, _P, _P, _I] + [_F] * 6 + [_I, _P, _P]),
-    "amk_gemm_x6_nt": (_I, [_P, _L, _P, _L, _P, _P, _L, _I, _I, _I, _P]),
+    "amk_gemm_x6_planes_bytes": (_L, [_I, _I]),
+    "amk_gemm_x6_split": (_I, [_P, _L, _I, _I, _P, _P]),
+    "amk_gemm_x6_nt": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P]),
     "amk_sample_step": (_I, [_P, _P, _F, _P, _c.c_uint64, _c.c_uint64, _F, _L, _I, _I, _P, _F, _P, _P, _P]),
     "amk_moe_route_ws_ints": (_L, [_L, _I, _I]),
     "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 8),

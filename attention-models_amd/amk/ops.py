@@ -756,7 +756,8 @@ GEMM_MODE = os.environ.get("AMK_GEMM", "f32")
 
 
 def gemm_x6_nt(a2, b2, bias=None):
-    """a2 (M, K) @ b2 (N, K)^T (+ bias): F.linear on 2-D operands through amk_gemm_x6_nt."""
+    """a2 (M, K) @ b2 (N, K)^T (+ bias): F.linear on 2-D operands through amk_gemm_x6_split + amk_gemm_x6_nt
+    (b2, the weight, is split into bf16 planes once per call; a2 inside the GEMM)."""
     _require_device(a2, b2, bias)
     if a2.stride(1) != 1:
         a2 = a2.contiguous()
@@ -764,10 +765,12 @@ def gemm_x6_nt(a2, b2, bias=None):
         b2 = b2.contiguous()
     M, K = a2.shape
     N = b2.shape[0]
-    c = torch.empty((M, N), device=a2.device, dtype=torch.float32)
     L = _lib.load()
+    planes = torch.empty((L.amk_gemm_x6_planes_bytes(N, K),), device=a2.device, dtype=torch.uint8)
+    c = torch.empty((M, N), device=a2.device, dtype=torch.float32)
     with _timed(f"gemm_x6_nt M{M} N{N} K{K}"):
-        rc = L.amk_gemm_x6_nt(_ptr(a2), a2.stride(0), _ptr(b2), b2.stride(0), _ptr(bias), _ptr(c), N, M, N, K, _stream())
+        _lib.check(L.amk_gemm_x6_split(_ptr(b2), b2.stride(0), N, K, _ptr(planes), _stream()), "amk_gemm_x6_split")
+        rc = L.amk_gemm_x6_nt(_ptr(a2), a2.stride(0), _ptr(planes), _ptr(bias), _ptr(c), N, M, N, K, _stream())
     _lib.check(rc, "amk_gemm_x6_nt")
     return c
 

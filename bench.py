@@ -326,6 +326,23 @@ def main():
             "attention forward with split-bf16 (bf16x6) products, f32-level error; the backward then recomputes S; "
             "not the headline value")
         note("split-bf16 forward variant done")
+        variants["variant_split_bf16_linear_gemms"] = variant(
+            lambda: setattr(amk_ops, "GEMM_MODE", "bf16x6"), lambda: setattr(amk_ops, "GEMM_MODE", "f32"),
+            "every nn.Linear of the generator (projections, FFN, patch / quant layers): forward and input gradient on the "
+            "split-bf16 GEMM csrc/gemm_x6.hip (f32 operands, six exact bf16 partial products per product, f32 "
+            "accumulation: f32-level error, tests/test_gemm_x6_gpu.py) instead of the library's exact-f32 GEMM; weight "
+            "gradients stay with the library; its bound is the bf16 MFMA peak / 6; not the headline value")
+        note("split-bf16 GEMM variant done")
+
+        def both_on():
+            amk_ops.GEMM_MODE, amk_ops.ATTENTION_FORWARD = "bf16x6", "bf16x6"
+
+        def both_off():
+            amk_ops.GEMM_MODE, amk_ops.ATTENTION_FORWARD = "f32", "f32"
+
+        variants["variant_split_bf16_gemms_and_attention_forward"] = variant(
+            both_on, both_off, "the two split-bf16 variants above together; not the headline value")
+        note("combined split-bf16 variant done")
 
     kernels = None
     if rank == 0 and not args.no_kernels:

@@ -377,14 +377,18 @@ int amk_sample_step(const float* logits, const float* null_logits, float cfg_sca
 /* --------------------------------------------------------------------------
  * Dense GEMM with split-bf16 products (the projections around the attention
  * core and the FFN -- nn.Linear in models/softmax_attention.py:30-42,80 and models/vitvqgan.py:20-61):
- *   C[m, n] = sum_k A[m, k] * B[n, k] (+ bias[n])        A (M, K), B (N, K), C (M, N), all f32, row-major
- * i.e. F.linear(A, B, bias); the input gradient dX = dY W is the same call with B = W^T.
+ *   C[m, n] = sum_k A[m, k] * W[n, k] (+ bias[n])        A (M, K), W (N, K), C (M, N), all f32, row-major
+ * i.e. F.linear(A, W, bias); the input gradient dX = dY W is the same call with W^T in W's place.
  * Every operand is split into three bf16 parts (24 mantissa bits) and every product is the sum of six
  * exact partial products accumulated in f32 (v_mfma_f32_32x32x16_bf16): f32-level error (tests compare
  * with float64), 6/16 of the matrix-pipe time of the exact-f32 MFMA.  Its bound is the bf16 MFMA peak / 6.
- * lda / ldb / ldc: row strides in elements (multiples of 4); K a multiple of 4; A, B 16-byte aligned.
+ * The weight is split once per call by amk_gemm_x6_split into `planes` (amk_gemm_x6_planes_bytes(N, K)
+ * bytes: three bf16 planes, K padded to 32); the activations are split inside the GEMM.
+ * lda / ldw / ldc: row strides in elements (multiples of 4); K a multiple of 4; pointers 16-byte aligned.
  * -------------------------------------------------------------------------- */
-int amk_gemm_x6_nt(const float* A, int64_t lda, const float* B, int64_t ldb, const float* bias,
+int64_t amk_gemm_x6_planes_bytes(int N, int K);
+int amk_gemm_x6_split(const float* W, int64_t ldw, int N, int K, void* planes, void* stream);
+int amk_gemm_x6_nt(const float* A, int64_t lda, const void* w_planes, const float* bias,
                    float* C, int64_t ldc, int M, int N, int K, void* stream);
 
 #ifdef __cplusplus
