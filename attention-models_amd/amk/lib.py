@@ -30,6 +30,7 @@ SIGNATURES = {
     "amk_attn_fwd_keep": (_I, [_P] * 8 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_attn_fwd_x6_ws_bytes": (_L, [_I, _I, _I]),
     "amk_attn_fwd_x6": (_I, [_P] * 8 + [_I] * 5 + [_L] * 12 + [_F, _P]),
+    "amk_attn_bwd_ws_floats": (_L, [_I, _I, _I, _I, _I]),
     "amk_attn_bwd": (_I, [_P] * 12 + [_I] * 5 + [_L] * 24 + [_F, _I, _P]),
     "amk_attn_bwd_kept": (_I, [_P] * 13 + [_I] * 5 + [_L] * 24 + [_F, _I, _P]),
     "amk_vq_num_partials": (_L, [_L]),

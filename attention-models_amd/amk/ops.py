@@ -138,7 +138,7 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=False):
     ws = torch.empty((L.amk_attn_fwd_x6_ws_bytes(B, H, J),), device=q.device, dtype=torch.uint8) if x6 else None
     scores = None
     if (keep_scores and D == 64 and not x6 and causal_mask is None and ATTENTION_KEEP_SCORES
-            and not DETERMINISTIC_ATTENTION_BACKWARD):
+            and not ATTENTION_BACKWARD_TWO_KERNEL):
         nbytes = L.amk_attn_scores_bytes(B, H, I, J)
         if nbytes <= ATTENTION_KEEP_SCORES_MAX_BYTES:
             scores = torch.empty((nbytes // 4,), device=q.device, dtype=torch.float32)
@@ -165,16 +165,22 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=False):
     return q, k, v, o, stats, scores
 
 
-# Backward path of the attention core: False (default) = one fused pass, each product computed once,
-# dq accumulated with f32 atomics (last-bit run-to-run differences in dq); True = two recompute
-# kernels, no atomics, bitwise reproducible (include/amk.h, amk_attn_bwd `stages`).
-DETERMINISTIC_ATTENTION_BACKWARD = False
+# Backward path of the attention core (include/amk.h, amk_attn_bwd `stages`): one fused pass.
+# Default: dq accumulated with f32 atomics into a zeroed buffer -- the fastest form (1.135 ms at the ViT-VQGAN layer
+# shape); dk, dv are reproducible, dq differs in the last bits from run to run.  Reproducible mode (4 % slower,
+# 1.179 ms): dq as plain stores -- directly when one workgroup holds all keys of a (batch, head), else per-key-block
+# partials summed in order by a second launch -- every gradient bitwise reproducible.  It is taken when
+# DETERMINISTIC_ATTENTION_BACKWARD is set (AMK_DETERMINISTIC=1) or torch.use_deterministic_algorithms(True) is on,
+# PyTorch's own convention for atomics-based backward kernels.
+DETERMINISTIC_ATTENTION_BACKWARD = os.environ.get("AMK_DETERMINISTIC", "0") == "1"
+ATTENTION_BACKWARD_TWO_KERNEL = False
 
 
 def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, scale, stages=None, delta=None,
                    scores=None):
     if stages is None:
-        stages = 7 if DETERMINISTIC_ATTENTION_BACKWARD else 9
+        det = DETERMINISTIC_ATTENTION_BACKWARD or torch.are_deterministic_algorithms_enabled()
+        stages = 7 if ATTENTION_BACKWARD_TWO_KERNEL else (73 if det else 9)
     if stages & 8 and not stages & 48:
         stages |= {128: 16, 256: 32}.get(ATTENTION_BACKWARD_KEYS, 0)
     if not stages & 8:
@@ -182,9 +188,10 @@ def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, sc
     B, H, I, D = q.shape
     J = k.shape[2]
     d_o = _as_kernel_view(d_o)
-    if delta is None:
-        delta = torch.empty((B, H, I), device=q.device, dtype=torch.float32)
     L = _lib.load()
+    need = L.amk_attn_bwd_ws_floats(B, H, I, J, int(stages))
+    if delta is None or delta.numel() < need:
+        delta = torch.empty((need,), device=q.device, dtype=torch.float32)
 
     def call(st):
         fn, head = (L.amk_attn_bwd_kept, (_ptr(scores),)) if scores is not None and st & 8 else (L.amk_attn_bwd, ())

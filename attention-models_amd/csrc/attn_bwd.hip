@@ -406,6 +406,8 @@ static int attn_bwd_impl(const float* scores, const float* q, const float* k, co
   p.nqblk = (I + BLK - 1) / BLK;
   p.nkblk = (J + BLK - 1) / BLK;
   p.scores = scores;
+  // reproducible dq from the one-pass kernel: the partials live behind the deltas in the workspace
+  p.dq_part = (stages & AMK_ATTN_BWD_DQ_REPRO) ? delta_ws + (((int64_t)B * H * I + 3) & ~(int64_t)3) : nullptr;
   AMK_CHECK_ARG(!scores || aligned16(scores), "amk_attn_bwd_kept: the scores buffer must be 16-byte aligned");
   AMK_CHECK_ARG(!scores || (stages & AMK_ATTN_BWD_FUSED), "amk_attn_bwd_kept: kept scores are read by the fused pass only");
   AMK_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o) && aligned16(d_o) && aligned16(dq) &&
@@ -442,6 +444,17 @@ static int attn_bwd_impl(const float* scores, const float* q, const float* k, co
   }
   AMK_CHECK_LAUNCH("amk_attn_bwd");
   return AMK_OK;
+}
+
+extern "C" int64_t amk_attn_bwd_ws_floats(int B, int H, int I, int J, int stages) {
+  if (B <= 0 || H <= 0 || I <= 0 || J <= 0) return 0;
+  int64_t n = ((int64_t)B * H * I + 3) & ~(int64_t)3;
+  if ((stages & AMK_ATTN_BWD_FUSED) && (stages & AMK_ATTN_BWD_DQ_REPRO)) {
+    const int keys = fused_keys_per_wg(J, (stages & AMK_ATTN_BWD_KEYS256) ? 256 : ((stages & AMK_ATTN_BWD_KEYS128) ? 128 : 0));
+    const int nk = (J + keys - 1) / keys;
+    if (nk > 1) n += (int64_t)nk * B * I * H * D;
+  }
+  return n;
 }
 
 extern "C" int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,

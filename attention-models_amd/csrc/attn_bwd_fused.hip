@@ -43,7 +43,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
-template <int NW, bool KEPT>
+// DQ: 0 = f32 atomic adds into a zeroed dq (fastest; dq differs in the last bits from run to run);
+//     1 = plain stores -- of dq itself when the workgroup holds every key of its (batch, head) (J <= 32 NW: no
+//         atomics, no memset), else of this key block's partial into p.dq_part[kb], summed in key-block order
+//         by attn_bwd_dq_reduce_kernel: bitwise reproducible.
+template <int NW, bool KEPT, int DQ>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p) {
   using G = FusedGeom<NW>;
   constexpr int NT = G::NT, KB = G::KB, DS_STRIDE = G::DS_STRIDE, KPG = G::KPG;
@@ -105,7 +109,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
   const float* gbase = p.d_o + (int64_t)b * p.dos.sb + (int64_t)h * p.dos.sh;
   const float* stbase = p.stats + ((int64_t)b * p.H + h) * p.I * 2;
   const float* dlbase = p.delta + ((int64_t)b * p.H + h) * p.I;
-  float* dqbase = p.dq + (int64_t)b * p.dqs.sb + (int64_t)h * p.dqs.sh;
+  float* dqbase = (DQ == 1 && p.nkblk > 1 ? p.dq_part + (int64_t)kb * p.B * p.I * p.H * D : p.dq) +
+                  (int64_t)b * p.dqs.sb + (int64_t)h * p.dqs.sh;
   // dq rows of this (batch, head) through a buffer descriptor: adds to rows beyond the sequence are
   // dropped by the hardware range check, so the atomics need no branch either
   const __amdgpu_buffer_rsrc_t dq_rsrc =
@@ -323,11 +328,20 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
       const int rstep = (int)(p.dqs.st * 4);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if (G::NBLK == 2) {
-          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(q0[r] * sc, dq_rsrc, off + r * rstep, 0, 0);
-          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(q1[r] * sc, dq_rsrc, off + r * rstep + 64, 0, 0);
-        } else {
-          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((q0[r] + q1[r]) * sc, dq_rsrc, off + r * rstep, 0, 0);
+        if (DQ == 0) {
+          if (G::NBLK == 2) {
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(q0[r] * sc, dq_rsrc, off + r * rstep, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(q1[r] * sc, dq_rsrc, off + r * rstep + 64, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32((q0[r] + q1[r]) * sc, dq_rsrc, off + r * rstep, 0, 0);
+          }
+        } else {  // plain stores through the same range-checked descriptor
+          if (G::NBLK == 2) {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q0[r] * sc), dq_rsrc, off + r * rstep, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, q1[r] * sc), dq_rsrc, off + r * rstep + 64, 0, 0);
+          } else {
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, (q0[r] + q1[r]) * sc), dq_rsrc, off + r * rstep, 0, 0);
+          }
         }
       }
     }
@@ -347,30 +361,56 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
   }
 }
 
-template <int NW, bool KEPT>
+// dq[i] = sum over key blocks, in key-block order, of the partials the DQ = 1 kernel stored
+__global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const float* __restrict__ part, int nk, int64_t n4,
+                                                                 float* __restrict__ dq) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+    float4 acc = ld4(part + 4 * i);
+    for (int k = 1; k < nk; ++k) {
+      const float4 x = ld4(part + ((int64_t)k * n4 + i) * 4);
+      acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+    }
+    st4(dq + 4 * i, acc);
+  }
+}
+
+template <int NW, bool KEPT, int DQ>
 static bool launch_variant(BwdParams p, hipStream_t st) {
   using G = FusedGeom<NW>;
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NW, KEPT>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NW, KEPT, DQ>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   G::LDS_FLOATS * (int)sizeof(float)) == hipSuccess;
   if (!attr_ok) return false;
-  if (hipMemsetAsync(p.dq, 0, (size_t)p.B * p.I * p.H * D * sizeof(float), st) != hipSuccess) return false;
   p.nkblk = (p.J + G::KB - 1) / G::KB;
+  const int64_t ndq = (int64_t)p.B * p.I * p.H * D;
+  if (DQ == 0 && hipMemsetAsync(p.dq, 0, (size_t)ndq * sizeof(float), st) != hipSuccess) return false;
   const int64_t nk = (int64_t)p.B * p.H * p.nkblk;
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<NW, KEPT>), dim3((unsigned)nk), dim3(G::NT), G::LDS_FLOATS * sizeof(float), st, p);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<NW, KEPT, DQ>), dim3((unsigned)nk), dim3(G::NT), G::LDS_FLOATS * sizeof(float), st, p);
+  if (DQ == 1 && p.nkblk > 1) {
+    const int64_t n4 = ndq / 4;
+    const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(grid), dim3(256), 0, st, p.dq_part, p.nkblk, n4, p.dq);
+  }
   return true;
 }
 
-// Launch the fused kernel.  dq must be the dense (B, I, H, 64) layout so that it can be zeroed
-// with one memset; returns false (nothing launched) when the layout or the masks rule it out.
-// keys_per_wg: 128 (4 waves, two workgroups per CU) or 256 (8 waves, one per CU; half the dq atomics);
-// 0 = pick (256 when the sequence has at least 256 keys).
+int fused_keys_per_wg(int J, int keys_per_wg) { return keys_per_wg ? keys_per_wg : (J >= 256 ? 256 : 128); }
+
+// Launch the fused kernel.  dq must be the dense (B, I, H, 64) layout (one memset / one reduce pass);
+// returns false (nothing launched) when the layout or the masks rule it out.
+// keys_per_wg: 128 (4 waves, two workgroups per CU) or 256 (8 waves, one per CU; half the dq adds);
+// 0 = pick (256 when the sequence has at least 256 keys).  p.dq_part != null: reproducible dq (DQ = 1).
 bool launch_attn_bwd_fused(const BwdParams& p, int keys_per_wg, hipStream_t st) {
   if (p.causal_mask) return false;
   if (!(p.dqs.sh == D && p.dqs.st == (int64_t)p.H * D && p.dqs.sb == (int64_t)p.I * p.H * D)) return false;
-  if (keys_per_wg == 0) keys_per_wg = p.J >= 256 ? 256 : 128;
-  if (keys_per_wg == 256) return p.scores ? launch_variant<8, true>(p, st) : launch_variant<8, false>(p, st);
-  return p.scores ? launch_variant<4, true>(p, st) : launch_variant<4, false>(p, st);
+  keys_per_wg = fused_keys_per_wg(p.J, keys_per_wg);
+  const bool det = p.dq_part != nullptr;
+  if (keys_per_wg == 256) {
+    if (det) return p.scores ? launch_variant<8, true, 1>(p, st) : launch_variant<8, false, 1>(p, st);
+    return p.scores ? launch_variant<8, true, 0>(p, st) : launch_variant<8, false, 0>(p, st);
+  }
+  if (det) return p.scores ? launch_variant<4, true, 1>(p, st) : launch_variant<4, false, 1>(p, st);
+  return p.scores ? launch_variant<4, true, 0>(p, st) : launch_variant<4, false, 0>(p, st);
 }
 
 }  // namespace amk_attn

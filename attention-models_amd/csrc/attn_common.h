@@ -45,6 +45,7 @@ struct BwdParams {
   float pinf;  // +infinity, passed at run time (see vmax)
   int nqblk, nkblk;  // ceil(I / BLK), ceil(J / BLK)
   const float* scores;  // kept scores of the forward (see ScoreTiles) or null: S is recomputed
+  float* dq_part;       // fused pass, reproducible dq: per-key-block partials (nkblk, B, I, H, 64), or null: atomics
 };
 
 // Kept scores: the forward can leave S^T = (q*scale*log2e) k^T (before any fill) in HBM for the backward,
@@ -123,6 +124,7 @@ void launch_attn_fwd_x6(const FwdParams& p, int64_t nwg, hipStream_t st);
 
 // attn_bwd_fused.hip: one-pass backward (dQ by atomics); false = not applicable, nothing launched.
 bool launch_attn_bwd_fused(const BwdParams& p, int keys_per_wg, hipStream_t st);
+int fused_keys_per_wg(int J, int keys_per_wg);
 
 // attn_generic.hip: head dims 32 and 128 (forward + the two recompute kernels of the backward)
 bool attn_gen_supported(int Dh);

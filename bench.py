@@ -84,10 +84,12 @@ def kernel_rooflines(B, dev, iters):
     scale = D ** -0.5
     q, k, v, o, stats, scores = ops._attn_forward(q, k, v, None, None, scale, keep_scores=True)
     dq, dk, dv = (torch.empty_like(q) for _ in range(3))
-    delta = torch.empty(B, H, T, device=dev)
+    from amk import lib as amk_lib
+    delta = torch.empty(amk_lib.load().amk_attn_bwd_ws_floats(B, H, T, T, 72), device=dev)  # deltas + dq partials
     bwd = lambda st, sc=None: ops._attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, None, None, scale, stages=st,
                                                  delta=delta, scores=sc)
     bwd(1)
+    main = 72 if ops.DETERMINISTIC_ATTENTION_BACKWARD else 8  # the default path: fused pass (+ reproducible dq)
     core = 4.0 * B * H * T * T * D  # algorithmic FLOP of the forward
     layers_f, layers_b = 4 * VIT["depth"], 2 * VIT["depth"]  # per step: 2 model fwd + 1 bwd, enc+dec
     out = []
@@ -105,14 +107,18 @@ def kernel_rooflines(B, dev, iters):
                     note="the forward with split-bf16 products (amk_attn_fwd_x6); its bound is the bf16 MFMA peak / 6, "
                          "not the f32 MFMA peak the fraction below is taken against"))
     if scores is not None:
-        t = time_launches(lambda: bwd(8, scores), iters)
+        t = time_launches(lambda: bwd(main, scores), iters)
         out.append(dict(kernel="attn_bwd_fused_kernel(kept scores)", launches_per_step=layers_b, avg_ms=t * 1e3,
                         flop=2 * core, note="8*B*h*I*J*d (dV,dP,dQ,dK: the four products it runs; S is read back from "
                                             "the forward's score tiles); includes the dq memset"))
-    t = time_launches(lambda: bwd(8), iters)
+        t = time_launches(lambda: bwd(72, scores), iters)
+        out.append(dict(kernel="attn_bwd_fused_kernel(kept scores, reproducible dq)", launches_per_step=0, avg_ms=t * 1e3,
+                        flop=2 * core, note="the same pass with dq as per-key-block partials + an ordered sum launch "
+                                            "(no atomics, no memset; AMK_DETERMINISTIC=1)"))
+    t = time_launches(lambda: bwd(main), iters)
     out.append(dict(kernel="attn_bwd_fused_kernel", launches_per_step=0 if scores is not None else layers_b,
                     avg_ms=t * 1e3, flop=2 * core,
-                    note="8*B*h*I*J*d (dV,dP,dQ,dK; recomputed S not credited); includes the dq memset"))
+                    note="8*B*h*I*J*d (dV,dP,dQ,dK; recomputed S not credited)"))
     t = time_launches(lambda: bwd(2), iters)
     out.append(dict(kernel="attn_bwd_dkdv_kernel", launches_per_step=0, avg_ms=t * 1e3, flop=core,
                     note="credited dV,dK products: 4*B*h*I*J*d (recomputed S, dP not credited)"))
@@ -316,6 +322,13 @@ def main():
             "generator forward run once per step and shared by the discriminator and generator phases (the "
             "reference runs it twice on unchanged weights); not the headline value")
         note("shared-forward variant done")
+        variants["variant_reproducible_dq"] = variant(
+            lambda: setattr(amk_ops, "DETERMINISTIC_ATTENTION_BACKWARD", True),
+            lambda: setattr(amk_ops, "DETERMINISTIC_ATTENTION_BACKWARD", False),
+            "the headline step with the attention backward storing per-key-block dq partials and summing them in order "
+            "(bitwise reproducible gradients; AMK_DETERMINISTIC=1 or torch.use_deterministic_algorithms(True)) instead of "
+            "adding dq by f32 atomics")
+        note("reproducible-dq variant done")
         variants["variant_recomputed_scores"] = variant(
             lambda: setattr(amk_ops, "ATTENTION_KEEP_SCORES", False), lambda: setattr(amk_ops, "ATTENTION_KEEP_SCORES", True),
             "the headline step with the attention backward recomputing S = QK^T (five products) instead of reading "

@@ -110,7 +110,8 @@ int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, fl
 /* Backward of amk_attn_fwd (autograd of the same reference lines).
  * Inputs: q,k,v,o,stats as in the forward, d_o (gradient of o, same addressing
  * as o with its own strides).  Outputs: dq (q-like), dk (k-like), dv (v-like),
- * each fully overwritten.  delta_ws: workspace of B*H*I floats.
+ * each fully overwritten.  delta_ws: workspace of amk_attn_bwd_ws_floats(B, H, I, J, stages) floats
+ * (B*H*I rounded up to 4, unless AMK_ATTN_BWD_DQ_REPRO asks for more).
  * Gradients do not flow through filled (-1e9) positions, as in masked_fill.
  * `stages` selects the launches.  bit 0: delta = rowsum(dO*O) into delta_ws (must have run
  * before any other bit).  Then EITHER bit 3 (AMK_ATTN_BWD_FUSED): one pass, each of the five
@@ -128,6 +129,13 @@ int amk_attn_fwd_x6(const float* q, const float* k, const float* v, float* o, fl
  * number of atomic adds per dq element (J / 256 instead of J / 128). */
 #define AMK_ATTN_BWD_KEYS128 16
 #define AMK_ATTN_BWD_KEYS256 32
+/* fused pass only: bitwise reproducible dq.  No atomics: a workgroup that holds every key of its (batch, head)
+ * (J <= keys per workgroup) stores dq directly; otherwise every key block stores its partial and a second
+ * launch sums the partials in key-block order.  delta_ws must then hold amk_attn_bwd_ws_floats(...) floats
+ * (the deltas followed by the partials). */
+#define AMK_ATTN_BWD_DQ_REPRO 64
+#define AMK_ATTN_BWD_FAST_REPRO 73  /* delta + fused + reproducible dq */
+int64_t amk_attn_bwd_ws_floats(int B, int H, int I, int J, int stages);
 int amk_attn_bwd(const float* q, const float* k, const float* v, const float* o,
                  const float* stats, const float* d_o,
                  float* dq, float* dk, float* dv, float* delta_ws,

@@ -15,23 +15,24 @@ TOL = 2e-5
 
 
 @pytest.fixture(params=["fused", "fused-kept-128", "fused-recompute-128", "fused-recompute-256", "deterministic",
-                        "fused-x6fwd"], autouse=True)
+                        "deterministic-128", "two-kernel", "fused-x6fwd"], autouse=True)
 def backward_path(request):
     """Every test runs with every backward path of the attention core (amk_attn_bwd `stages`): the fused
     pass reading the scores the forward kept (the default) or recomputing them, with 128 or 256 keys per
-    workgroup; the two reproducible recompute kernels; and the split-bf16 forward (amk_attn_fwd_x6) in
-    front of the fused backward."""
+    workgroup; the same pass with reproducible dq (direct stores / per-key-block partials); the two
+    reproducible recompute kernels; and the split-bf16 forward (amk_attn_fwd_x6) in front of the fused backward."""
     from amk import ops
 
     old = (ops.DETERMINISTIC_ATTENTION_BACKWARD, ops.ATTENTION_FORWARD, ops.ATTENTION_KEEP_SCORES,
-           ops.ATTENTION_BACKWARD_KEYS)
-    ops.DETERMINISTIC_ATTENTION_BACKWARD = request.param == "deterministic"
+           ops.ATTENTION_BACKWARD_KEYS, ops.ATTENTION_BACKWARD_TWO_KERNEL)
+    ops.DETERMINISTIC_ATTENTION_BACKWARD = request.param.startswith("deterministic")
+    ops.ATTENTION_BACKWARD_TWO_KERNEL = request.param == "two-kernel"
     ops.ATTENTION_FORWARD = "bf16x6" if request.param.endswith("x6fwd") else "f32"
     ops.ATTENTION_KEEP_SCORES = "recompute" not in request.param
     ops.ATTENTION_BACKWARD_KEYS = 128 if request.param.endswith("128") else (256 if request.param.endswith("256") else 0)
     yield request.param
     (ops.DETERMINISTIC_ATTENTION_BACKWARD, ops.ATTENTION_FORWARD, ops.ATTENTION_KEEP_SCORES,
-     ops.ATTENTION_BACKWARD_KEYS) = old
+     ops.ATTENTION_BACKWARD_KEYS, ops.ATTENTION_BACKWARD_TWO_KERNEL) = old
 
 
 def _core_case(device, B, H, I, J, key_mask=None, causal=None, seed=0, layout="bthd", D=64):
@@ -258,7 +259,7 @@ def test_kept_scores_equal_recomputed_scores(device, backward_path, B, H, I, J):
 def test_core_other_head_dims(device, backward_path, D, B, H, I, J, masks):
     """dim_head 32 and 128 (the reference takes any dim_head, models/softmax_attention.py:23): the generic
     kernels of csrc/attn_generic.hip against the oracle, every mask combination, ragged sizes."""
-    if backward_path not in ("fused", "deterministic"):
+    if backward_path not in ("fused", "two-kernel"):
         pytest.skip("head dims other than 64 have one forward and one (reproducible) backward")
     km = None
     if "k" in masks:
@@ -296,3 +297,51 @@ def test_module_other_head_dims(device, backward_path, dim_head):
         (gx,) = torch.autograd.grad((got * cot.to(device)).sum(), [xd])
         assert_close(got, want, TOL, "output")
         assert_close(gx, gx_ref, TOL, "grad x")
+
+
+@pytest.mark.parametrize("B,H,I,J", [(2, 2, 200, 130), (1, 2, 1024, 1024), (2, 1, 300, 77), (1, 1, 40, 600)])
+def test_reproducible_fused_backward(device, backward_path, B, H, I, J):
+    """AMK_ATTN_BWD_DQ_REPRO: the one-pass backward without atomics -- dq stored directly (all keys in one
+    workgroup: J = 77, 130 at 256 keys per workgroup) or as per-key-block partials summed in order -- gives
+    bit-identical dq, dk, dv on every run, equal to the atomics path within rounding."""
+    if backward_path != "fused":
+        pytest.skip("one pass is enough: the test drives every variant itself")
+    from amk import ops
+
+    D = 64
+    mk = lambda seed, T: seeded((B, T, H, D), seed).to(device).permute(0, 2, 1, 3)
+    q, k, v, d_o = mk(1, I), mk(2, J), mk(3, J), mk(4, I)
+    scale = D ** -0.5
+    q, k, v, o, stats, scores = ops._attn_forward(q, k, v, None, None, scale, keep_scores=True)
+
+    def run(stages, sc):
+        dq, dk, dv = (torch.full_like(t, float("nan")) for t in (q, k, v))
+        ops._attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, None, None, scale, stages=stages, scores=sc)
+        return dq, dk, dv
+
+    ref = run(9, scores)                       # atomics
+    for keys in (16, 32):
+        for sc in (scores, None):
+            a, b_ = run(73 | keys, sc), run(73 | keys, sc)
+            for x, y, z, name in zip(a, b_, ref, ("dq", "dk", "dv")):
+                assert torch.equal(x, y), (name, keys)
+                assert_close(x, z, 3e-6, f"{name} keys bit {keys}")
+
+
+def test_torch_deterministic_mode_selects_reproducible_backward(device, backward_path):
+    """torch.use_deterministic_algorithms(True) -- PyTorch's switch for atomics-based backward kernels -- makes
+    ops.attention take the reproducible dq path: two backward passes give bit-identical gradients."""
+    if backward_path != "fused":
+        pytest.skip("one pass")
+    from amk import ops
+
+    q, k, v = (seeded((2, 4, 1024, 64), s).to(device).requires_grad_(True) for s in (1, 2, 3))
+    cot = seeded((2, 4, 1024, 64), 4).to(device)
+    assert not ops.DETERMINISTIC_ATTENTION_BACKWARD
+    torch.use_deterministic_algorithms(True)
+    try:
+        g1 = torch.autograd.grad((ops.attention(q, k, v, 0.125) * cot).sum(), [q, k, v])
+        g2 = torch.autograd.grad((ops.attention(q, k, v, 0.125) * cot).sum(), [q, k, v])
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))

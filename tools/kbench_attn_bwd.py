@@ -23,7 +23,9 @@ if __name__ == "__main__":
     ap.add_argument("--T", type=int, default=1024)
     ap.add_argument("--H", type=int, default=8)
     a = ap.parse_args()
-    from amk import ops
+    from amk import lib, ops
+
+    L_ws = lambda B_, H_, I_, J_: lib.load().amk_attn_bwd_ws_floats(B_, H_, I_, J_, 8 | 64 | 32)
 
     dev = torch.device("cuda:0")
     B, H, T, D = a.batch, a.H, a.T, 64
@@ -47,5 +49,12 @@ if __name__ == "__main__":
                                             delta=delta, scores=scores if kept else None)
             t = time_launches(fn, a.iters)
             rows.append((f"attn_bwd_fused keys={keys} {'kept' if kept else 'recompute'}", t, 2 * core))
+    big = torch.empty(L_ws(B, H, T, T), device=dev)
+    for kept in (False, True):
+        fn = lambda: ops._attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, None, None, scale, stages=8 | 64 | 32,
+                                        delta=big, scores=scores if kept else None)
+        ops._attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, None, None, scale, stages=1, delta=big)
+        t = time_launches(fn, a.iters)
+        rows.append((f"attn_bwd_fused keys=256 {'kept' if kept else 'recompute'} reproducible dq", t, 2 * core))
     for name, t, fl in rows:
         print(f"{name:44s} {t * 1e3:8.4f} ms  {fl / t / 1e12:7.2f} TFLOP/s  {fl / t / 1e12 / PEAK:.3f} of f32 MFMA peak", flush=True)

@@ -27,8 +27,9 @@ def short(name):
     if not m:
         return name
     base, targs = m.group(1), (m.group(2) or "").replace(" ", "")
-    if base == "attn_bwd_fused_kernel" and targs.endswith(",true>"):
-        return base + "(kept scores)"
+    if base == "attn_bwd_fused_kernel":   # <NW, KEPT, DQ>
+        t = targs.strip("<>").split(",")
+        return base + ("(kept scores)" if len(t) > 1 and t[1] == "true" else "")
     if base == "attn_fwd_kernel" and targs.endswith(",true>"):
         return "attn_fwd_keep_kernel"
     return base
