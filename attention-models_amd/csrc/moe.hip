@@ -186,18 +186,30 @@ struct GemmParams {
   const int32_t* offsets;
   const int32_t* perm;
   int E, N, Kd;
+  int ncol;              // output tiles per row tile (nt, nn: 1-D grid of units)
   int a_div, b_div;
   int64_t lda, ldb;
   int64_t a_bytes;       // size of the A buffer (wide kernels: buffer-descriptor range)
 };
 
-// Locate (expert, m-tile) for this workgroup: tiles are dealt expert by expert.
-__device__ __forceinline__ bool find_tile(const int32_t* offsets, int E, int tile, int& e, int& m0, int& cnt) {
+// Locate this workgroup's unit = (expert, output tile, 64-pair row tile).  The grid is 1-D over the units in
+// the order [expert][output tile][row tile]: the row tiles that read one weight panel W[e, tile, :] are
+// adjacent, and the ids are remapped (xcd_remap over the ACTUAL number of units -- the grid is an upper bound,
+// the surplus workgroups leave) so that adjacent units run on one XCD, behind one L2: as a 2-D grid the five
+// row tiles of a panel were dealt to five XCDs and each fetched the panel from HBM (PMC: 693 MB read per
+// forward for 185 MB of operands).
+__device__ __forceinline__ bool find_unit(const int32_t* offsets, int E, int ncol, int bid, int& e, int& m0, int& cnt, int& ct) {
+  int T = 0;
+  for (int j = 0; j < E; ++j) T += (offsets[j + 1] - offsets[j] + 63) >> 6;
+  const int total = T * ncol;
+  if (bid >= total) return false;
+  int u = xcd_remap(bid, total);
   for (int j = 0; j < E; ++j) {
     const int c = offsets[j + 1] - offsets[j];
     const int nt = (c + 63) >> 6;
-    if (tile < nt) { e = j; m0 = tile * 64; cnt = c; return true; }
-    tile -= nt;
+    const int blk = nt * ncol;
+    if (u < blk) { e = j; ct = u / nt; m0 = (u - ct * nt) * 64; cnt = c; return true; }
+    u -= blk;
   }
   return false;
 }
@@ -214,9 +226,9 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
   __shared__ int prow[64];
   float* As = smem;
   float* Ws = smem + 64 * LS;
-  int e, m0, cnt;
-  if (!find_tile(g.offsets, g.E, blockIdx.x, e, m0, cnt)) return;
-  const int n0 = blockIdx.y * BN;
+  int e, m0, cnt, ct;
+  if (!find_unit(g.offsets, g.E, g.ncol, blockIdx.x, e, m0, cnt, ct)) return;
+  const int n0 = ct * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
@@ -299,9 +311,9 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_wide_kernel(GemmParams g) {
   __shared__ int prow[64];
   float* As = smem;
   float* Ws = smem + 64 * LS;
-  int e, m0, cnt;
-  if (!find_tile(g.offsets, g.E, blockIdx.x, e, m0, cnt)) return;
-  const int n0 = blockIdx.y * BN;
+  int e, m0, cnt, ct;
+  if (!find_unit(g.offsets, g.E, g.ncol, blockIdx.x, e, m0, cnt, ct)) return;
+  const int n0 = ct * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
@@ -382,9 +394,9 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
   __shared__ int prow[64];
   float* As = smem;            // [64 pairs][32 n]
   float* Ws = smem + 64 * LS;  // [32 n][BC kk]
-  int e, m0, cnt;
-  if (!find_tile(g.offsets, g.E, blockIdx.x, e, m0, cnt)) return;
-  const int c0 = blockIdx.y * BC;  // output (kk) tile
+  int e, m0, cnt, ct;
+  if (!find_unit(g.offsets, g.E, g.ncol, blockIdx.x, e, m0, cnt, ct)) return;
+  const int c0 = ct * BC;  // output (kk) tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
@@ -672,12 +684,13 @@ extern "C" int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const
   g.A = A; g.W = W; g.bias = bias; g.Y = Y; g.offsets = offsets; g.perm = perm;
   g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
   const unsigned mt = (unsigned)((P + 63) / 64 + E);
+  AMK_CHECK_SUPPORTED((uint64_t)mt * ((N + 63) / 64) < (1ull << 31), "amk_grouped_gemm_nt: grid too large");
   // measured at the ViTMoE layer shape (P 8320, N = Kd = 1024, E 32): NB 1 0.207 ms, NB 2 0.240 ms
   g.a_bytes = ((P - 1) / a_div * lda + Kd) * 4;   // rows 0 .. (P-1)/a_div of A
   if (N >= 128 && Kd % 64 == 0 && g.a_bytes < (1ll << 31) && (int64_t)N * Kd * 4 < (1ll << 31) && !getenv("AMK_MOE_NARROW"))
-    hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3(mt, (N + 127) / 128), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    { g.ncol = (N + 127) / 128; hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else
-    hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt, (N + 63) / 64), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    { g.ncol = (N + 63) / 64; hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH("amk_grouped_gemm_nt");
   return AMK_OK;
 }
@@ -691,9 +704,10 @@ extern "C" int amk_grouped_gemm_nn(const float* A, int64_t lda, int a_div, const
   g.A = A; g.W = W; g.scale = scale; g.Y = Y; g.offsets = offsets; g.perm = perm;
   g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
   const unsigned mt = (unsigned)((P + 63) / 64 + E);
+  AMK_CHECK_SUPPORTED((uint64_t)mt * ((Kd + 127) / 128) < (1ull << 31), "amk_grouped_gemm_nn: grid too large");
   // same shape: NB 1 0.199 ms, NB 2 0.187 ms
-  if (Kd > 64) hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt, (Kd + 127) / 128), dim3(256), 0, static_cast<hipStream_t>(stream), g);
-  else hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt, 1), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  if (Kd > 64) { g.ncol = (Kd + 127) / 128; hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+  else { g.ncol = 1; hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH("amk_grouped_gemm_nn");
   return AMK_OK;
 }

@@ -30,4 +30,4 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
     for _ in range(2):
         tr.step(imgs)
     torch.cuda.synchronize()
-print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=45, max_name_column_width=60))
+print(prof.key_averages().table(sort_by="self_cuda_time_total", row_limit=90, max_name_column_width=60))
