@@ -187,9 +187,11 @@ struct GemmParams {
   const int32_t* perm;
   int E, N, Kd;
   int ncol;              // output tiles per row tile (nt, nn: 1-D grid of units)
+  int slots;             // workgroups the chip holds at once (2 per CU): tile-height choice of the wide kernels
   int a_div, b_div;
   int64_t lda, ldb;
   int64_t a_bytes;       // size of the A buffer (wide kernels: buffer-descriptor range)
+  int64_t y_bytes;       // size of the Y buffer (wide kernels)
 };
 
 // Locate this workgroup's unit = (expert, output tile, 64-pair row tile).  The grid is 1-D over the units in
@@ -300,90 +302,214 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
   }
 }
 
-// The same product for the wide shapes (N >= 128, Kd a multiple of 64): tile 64 pairs x 128 outputs x 64
-// deep -- four times the MFMAs per barrier pair and per staged byte of grouped_nt_kernel<1> -- every wave
-// 32 pairs x 64 outputs (two accumulators sharing the A fragment).  Operands are staged through buffer
-// descriptors (pairs beyond the tile and rows beyond N read as zeros: no compares or selects) and the
-// tile loop has no branch around a vector-memory instruction, so every wait is a counted one.
-__global__ __launch_bounds__(256, 2) void grouped_nt_wide_kernel(GemmParams g) {
-  constexpr int BK = 64, LS = BK + 4, BN = 128;
-  __shared__ __attribute__((aligned(16))) float smem[(64 + BN) * LS];
-  __shared__ int prow[64];
-  float* As = smem;
-  float* Ws = smem + 64 * LS;
-  int e, m0, cnt, ct;
-  if (!find_unit(g.offsets, g.E, g.ncol, blockIdx.x, e, m0, cnt, ct)) return;
+// The same product for the wide shapes (N >= 128, Kd a multiple of 64).  An expert's pairs are cut into 32-row
+// blocks and the blocks into tiles of RB = 1..4 blocks of (nearly) equal height -- 260 pairs are 9 blocks = three
+// tiles of 96 rows, not four tiles of 64 and one of 4 (five passes over the weight panel, the last one for 4
+// rows) -- x 128 outputs x 64 deep.  The four waves split the 128 OUTPUTS; every wave keeps RB accumulators that
+// share its B (weight) fragment: 32 RB MFMAs per wave between barrier pairs.  Operands are staged through buffer
+// descriptors (pairs beyond the tile and rows beyond N read as zeros: no compares or selects) and the tile loop
+// has no branch around a vector-memory instruction, so every wait is a counted one.
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+__device__ __forceinline__ int wave_sum(int v) {
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Every wave decodes the unit by itself: lane j holds expert j's tile count, one scan, one ballot (a serial
+// walk over the offsets is 2 E dependent scalar loads, microseconds before the first useful load).
+// The tile height is chosen per launch: an expert's nb 32-row blocks are cut into ceil(nb / m) tiles of nearly
+// equal height with m in 2..4 blocks.  Taller tiles stream the weight panel fewer times, but the units of a
+// launch then fill the `slots` workgroup slots of the chip in few, long rounds (768 units of 3 blocks on 512
+// slots take two rounds of which the second is half empty); every wave evaluates
+//   rounds(m) x (mean blocks per unit + 0.35)      [0.35 blocks: a unit's fixed cost]
+// for the four m from the same offsets and takes the smallest (ties: the taller tile).
+__device__ __forceinline__ bool find_unit_rb(const int32_t* offsets, int E, int ncol, int slots, int bid, int& e, int& ct, int& m0, int& rb, int& cnt) {
+  const int lane = threadIdx.x & 63;
+  int U[4] = {0, 0, 0, 0}, nbtot = 0;
+  for (int base = 0; base < E; base += 64) {
+    const int j = base + lane;
+    const int c = j < E ? offsets[j + 1] - offsets[j] : 0;
+    const int nb = (c + 31) >> 5;
+    nbtot += wave_sum(nb);
+#pragma unroll
+    for (int m = 1; m <= 4; ++m) U[m - 1] += wave_sum((nb + m - 1) / m);
+  }
+  int mbest = 4;
+  float best = 3.0e38f;
+#pragma unroll
+  for (int m = 4; m >= 2; --m) {  // (m = 1 is left out: it would double the grid bound the host must launch)
+    const int u = U[m - 1] * ncol;
+    if (u == 0) return false;
+    const float est = (float)((u + slots - 1) / slots) * ((float)(nbtot * ncol) / (float)u + 0.35f);
+    if (est < best) { best = est; mbest = m; }
+  }
+  const int total = U[mbest - 1] * ncol;
+  if (bid >= total) return false;
+  int u = xcd_remap(bid, total);
+  for (int base = 0; base < E; base += 64) {
+    const int j = base + lane;
+    const int c = j < E ? offsets[j + 1] - offsets[j] : 0;
+    const int nb = (c + 31) >> 5, parts = (nb + mbest - 1) / mbest;
+    const int incl = wave_incl_scan(parts * ncol, lane);
+    const int tot = __builtin_amdgcn_readlane(incl, 63);
+    if (u < tot) {
+      const unsigned long long m = __ballot(incl > u);
+      const int f = __builtin_ctzll(m);  // first expert whose running unit count passes u
+      e = base + f;
+      cnt = __shfl(c, f, 64);
+      const int parts_e = __shfl(parts, f, 64), nb_e = (cnt + 31) >> 5;
+      u -= __shfl(incl, f, 64) - parts_e * ncol;
+      ct = u / parts_e;
+      const int i = u - ct * parts_e, bs = nb_e / parts_e, extra = nb_e - bs * parts_e;
+      rb = bs + (i < extra ? 1 : 0);
+      m0 = 32 * (i * bs + min(i, extra));
+      return true;
+    }
+    u -= tot;
+  }
+  return false;
+}
+
+template <int RB>
+__device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct, int m0, int cnt, float* smem, int* prow) {
+  constexpr int BK = 32, LS = BK + 4, BN = 128, ROWS = 32 * RB;
+  constexpr int STAGE = (128 + BN) * LS;  // floats per LDS stage: A rows [0, 128), W rows [128, 256)
   const int n0 = ct * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
-  const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
-  if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
+  // per row of the tile, computed once by one thread: byte offset of its source row in A and of its output row in
+  // Y (rows past the expert's pairs: an offset past the buffers -- loads return zeros, stores are dropped)
+  constexpr unsigned PAST = 0x80000000u;      // row sentinel; buffers are < 2 GB, so PAST + (any in-range offset) stays past them
+  constexpr unsigned COL_PAST = 0x7FFF0000u;  // column sentinel: PAST + COL_PAST does not wrap
+  int* arow_off = prow;
+  int* yrow_off = prow + 128;
+  if (tid < ROWS) {
+    unsigned ao = PAST, yo = PAST;
+    if (m0 + tid < cnt) {
+      const int pp = g.perm[g.offsets[e] + m0 + tid];
+      ao = (unsigned)((int64_t)(pp / g.a_div) * g.lda * 4);
+      yo = (unsigned)((int64_t)pp * g.N * 4);
+    }
+    arow_off[tid] = (int)ao;
+    yrow_off[tid] = (int)yo;
+  }
   __syncthreads();
-  // staging: 16 threads per row (16 B each): A rows sr + 16 j (j < 4), W rows sr + 16 j (j < 8)
-  const int sr = tid >> 4, sc = (tid & 15) * 4;
+  // staging: 8 threads per row (16 B each): A rows sr + 32 j (j < RB), W rows sr + 32 j (j < 4)
+  const int sr = tid >> 3, sc = (tid & 7) * 4;
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, (int)((int64_t)g.N * g.Kd * 4), 0x00020000);
-  int aoff[4], woff[8];
+  constexpr int NS = RB + 4;  // staged float4 per thread and step: slots [0, RB) = A, [RB, NS) = W
+  int goff[NS];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int pp = prow[sr + 16 * j];
-    aoff[j] = pp >= 0 ? (int)(((int64_t)(pp / g.a_div) * g.lda + sc) * 4) : 0x7fffff00;  // past the buffer: zeros
-  }
+  for (int j = 0; j < RB; ++j) goff[j] = arow_off[sr + 32 * j] + sc * 4;  // (PAST + sc * 4 stays past the buffer)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) woff[j] = (int)(((int64_t)(n0 + sr + 16 * j) * g.Kd + sc) * 4);  // rows >= N: past the buffer
-  float4 ast[4], wst[8];
-  auto prefetch = [&](int k0) {
-#pragma unroll
-    // (the k offset goes into the vector offset: that is the part the hardware range check covers)
-    for (int j = 0; j < 4; ++j) ast[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, aoff[j] + k0 * 4, 0, 0));
-#pragma unroll
-    for (int j = 0; j < 8; ++j) wst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, woff[j] + k0 * 4, 0, 0));
+  for (int j = 0; j < 4; ++j) goff[RB + j] = (int)(((int64_t)(n0 + sr + 32 * j) * g.Kd + sc) * 4);  // rows >= N: past the buffer
+  float4 stg[NS];
+  // (the k offset goes into the vector offset: that is the part the hardware range check covers)
+  auto gload = [&](int i, int k0) {  // (two calls, not a select between the descriptors: that would make them "divergent")
+    if (i < RB) stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, goff[i] + k0 * 4, 0, 0));
+    else stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, goff[i] + k0 * 4, 0, 0));
   };
-  auto commit = [&]() {
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) st4(&As[(sr + 16 * j) * LS + sc], ast[j]);
-#pragma unroll
-    for (int j = 0; j < 8; ++j) st4(&Ws[(sr + 16 * j) * LS + sc], wst[j]);
+  auto lstore = [&](int i, float* stage) {
+    const int row = i < RB ? sr + 32 * i : 128 + sr + 32 * (i - RB);
+    st4(&stage[row * LS + sc], stg[i]);
   };
-  f32x16 acc0 = zero16(), acc1 = zero16();
-  prefetch(0);
   const int nk = g.Kd / BK;
-  for (int kt = 0; kt < nk; ++kt) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    prefetch(min(kt + 1, nk - 1) * BK);  // unconditional (the last step re-reads its own tile, unused)
-    if (!rows_here) continue;            // a tail tile with at most 32 pairs: this wave's row half is empty
-    const float* ar = &As[(32 * wm + ln) * LS + 32 * hf];
-    const float* wr = &Ws[(64 * wn + ln) * LS + 32 * hf];
+  // Weight panels start their walk over K at different slabs (the row tiles of one panel together), so that
+  // workgroups that start in step do not all read the same slab of their rows at the same time.
+  const int rot = (e * g.ncol + ct) % nk;
+  auto kof = [&](int kt) { int k = min(kt, nk - 1) + rot; k -= (k >= nk) ? nk : 0; return k * BK; };
+
+  f32x16 acc[RB];
 #pragma unroll
-    for (int s4 = 0; s4 < 8; ++s4) {
-      const float4 a = ld4(ar + 4 * s4);
-      const float4 b0 = ld4(wr + 4 * s4);
-      const float4 b1 = ld4(wr + 32 * LS + 4 * s4);
+  for (int j = 0; j < RB; ++j) acc[j] = zero16();
+  // pipeline: during step t (MFMAs on LDS stage t & 1) every thread moves its NS pieces of tile t + 1 from
+  // registers to the other stage and refills each register with its piece of tile t + 2 -- one ds_write and
+  // one buffer load between groups of MFMAs, ONE barrier per step, every vmcnt wait a counted one.
+#pragma unroll
+  for (int i = 0; i < NS; ++i) gload(i, kof(0));
+#pragma unroll
+  for (int i = 0; i < NS; ++i) lstore(i, smem);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) gload(i, kof(1));
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered in the state its back edge leaves
+  __syncthreads();
+  const int a_rd = ln * LS + 16 * hf, w_rd = (128 + 32 * wave + ln) * LS + 16 * hf;
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* cur = smem + (kt & 1) * STAGE;
+    float* nxt = smem + ((kt + 1) & 1) * STAGE;
+    const int k2 = kof(kt + 2);
+    float4 a[RB], b = ld4(cur + w_rd);
+#pragma unroll
+    for (int j = 0; j < RB; ++j) a[j] = ld4(cur + a_rd + 32 * j * LS);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float4 an[RB], bn = b;
+#pragma unroll
+      for (int j = 0; j < RB; ++j) an[j] = a[j];
+      if (s4 + 1 < 4) {
+        bn = ld4(cur + w_rd + 4 * (s4 + 1));
+#pragma unroll
+        for (int j = 0; j < RB; ++j) an[j] = ld4(cur + a_rd + 32 * j * LS + 4 * (s4 + 1));
+      }
+      // this group's share of the tile movement
+#pragma unroll
+      for (int i = s4 * NS / 4; i < (s4 + 1) * NS / 4; ++i) {
+        lstore(i, nxt);
+        gload(i, k2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        acc0 = mfma32(f4(a, x), f4(b0, x), acc0);
-        acc1 = mfma32(f4(a, x), f4(b1, x), acc1);
+#pragma unroll
+        for (int j = 0; j < RB; ++j) acc[j] = mfma32(f4(a[j], x), f4(b, x), acc[j]);
       }
+      __builtin_amdgcn_sched_barrier(0);
+      b = bn;
+#pragma unroll
+      for (int j = 0; j < RB; ++j) a[j] = an[j];
+    }
+    __syncthreads();
+  }
+  // epilogue: one add and one range-checked buffer store per element (rows past the pairs and columns past N
+  // carry offsets past the buffer and are dropped by the hardware: no compares, branches or 64-bit products)
+  const int n = n0 + 32 * wave + ln;
+  const float bv = (g.bias && n < g.N) ? g.bias[(int64_t)e * g.N + n] : 0.f;
+  const unsigned coff = n < g.N ? (unsigned)n * 4u : COL_PAST;
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.Y, 0, (int)g.y_bytes, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const unsigned yo = (unsigned)yrow_off[32 * j + acc_row(r, hf)];
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] + bv), y_rsrc, (int)(yo + coff), 0, 0);
     }
   }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const f32x16& acc = j ? acc1 : acc0;
-    const int n = n0 + 64 * wn + 32 * j + ln;
-    if (n < g.N) {
-      const float bv = g.bias ? g.bias[(int64_t)e * g.N + n] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = prow[32 * wm + acc_row(r, hf)];
-        if (p >= 0) g.Y[(int64_t)p * g.N + n] = acc[r] + bv;
-      }
-    }
-  }
+}
+
+__global__ __launch_bounds__(256, 2) void grouped_nt_wide_kernel(GemmParams g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (128 + 128) * 36];
+  __shared__ int prow[256];
+  int e, ct, m0, rb, cnt;
+  if (!find_unit_rb(g.offsets, g.E, g.ncol, g.slots, blockIdx.x, e, ct, m0, rb, cnt)) return;
+  // (wave-uniform by construction; said again here, or the weight panel's buffer descriptor counts as divergent
+  // and every load through it is wrapped in a waterfall loop)
+  e = __builtin_amdgcn_readfirstlane(e); ct = __builtin_amdgcn_readfirstlane(ct); m0 = __builtin_amdgcn_readfirstlane(m0);
+  rb = __builtin_amdgcn_readfirstlane(rb); cnt = __builtin_amdgcn_readfirstlane(cnt);
+  if (rb == 4) nt_panel_body<4>(g, e, ct, m0, cnt, smem, prow);
+  else if (rb == 3) nt_panel_body<3>(g, e, ct, m0, cnt, smem, prow);
+  else if (rb == 2) nt_panel_body<2>(g, e, ct, m0, cnt, smem, prow);
+  else nt_panel_body<1>(g, e, ct, m0, cnt, smem, prow);
 }
 
 // Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk]              tile: 64 pairs x 64*NB outputs
@@ -642,6 +768,16 @@ using namespace amk_moe;
 
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// workgroups of the wide kernels resident at once: two per CU (LDS-bound)
+static int wg_slots() {
+  static const int slots = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    return 2 * cus;
+  }();
+  return slots;
+}
+
 extern "C" int64_t amk_moe_route_ws_ints(int64_t U, int E, int k) { return ((U * k + 255) / 256) * E; }
 
 extern "C" int amk_moe_route(const float* logits, int64_t U, int E, int k,
@@ -687,8 +823,10 @@ extern "C" int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const
   AMK_CHECK_SUPPORTED((uint64_t)mt * ((N + 63) / 64) < (1ull << 31), "amk_grouped_gemm_nt: grid too large");
   // measured at the ViTMoE layer shape (P 8320, N = Kd = 1024, E 32): NB 1 0.207 ms, NB 2 0.240 ms
   g.a_bytes = ((P - 1) / a_div * lda + Kd) * 4;   // rows 0 .. (P-1)/a_div of A
-  if (N >= 128 && Kd % 64 == 0 && g.a_bytes < (1ll << 31) && (int64_t)N * Kd * 4 < (1ll << 31) && !getenv("AMK_MOE_NARROW"))
-    { g.ncol = (N + 127) / 128; hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+  g.y_bytes = P * N * 4;
+  if (N >= 128 && Kd % 32 == 0 && g.a_bytes < (1ll << 31) && g.y_bytes < 0x7FFF0000ll && (int64_t)N * Kd * 4 < (1ll << 31) && !getenv("AMK_MOE_NARROW"))
+    { g.ncol = (N + 127) / 128; g.slots = wg_slots();  // grid: the bound for two-block tiles; the surplus workgroups leave at once
+      hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3((unsigned)((P + 63) / 64 + E) * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else
     { g.ncol = (N + 63) / 64; hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH("amk_grouped_gemm_nt");

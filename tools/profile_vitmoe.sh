@@ -14,3 +14,4 @@ timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc TCC_EA0_ATOMIC_sum --output-format csv -d $O/pmcD -o d -- python3 $R/tools/kbench_moe.py --iters 3 > $O/pmcD.log 2>&1
 echo "pmc B-D done"
 rm -f $O/*/*_kernel_trace.csv.bak
+timeout -k 10 300 rocprofv3 --kernel-trace --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_VALU_MFMA_COEXEC_CYCLES --output-format csv -d $O/pmcE -o e -- python3 $R/tools/kbench_moe.py --iters 3 > $O/pmcE.log 2>&1 || echo "pmc E failed (optional)"
