@@ -192,6 +192,8 @@ struct GemmParams {
   int64_t lda, ldb;
   int64_t a_bytes;       // size of the A buffer (wide kernels: buffer-descriptor range)
   int64_t y_bytes;       // size of the Y buffer (wide kernels)
+  int64_t b_bytes, s_bytes;  // wgrad: sizes of the X and scale buffers
+  int a_shift, b_shift;  // log2 of a_div / b_div when they are powers of two, else -1
 };
 
 // Locate this workgroup's unit = (expert, output tile, 64-pair row tile).  The grid is 1-D over the units in
@@ -512,6 +514,142 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_wide_kernel(GemmParams g) {
   else nt_panel_body<1>(g, e, ct, m0, cnt, smem, prow);
 }
 
+// The input-gradient product Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk] on the same pipeline: tiles of
+// RB 32-row blocks x 128 outputs (kk) x 32 deep (n).  W is consumed as stored, (n, kk) rows: the B operand of a
+// step is a column of the staged (32 n x 128 kk) slab -- ds_read_b32, consecutive lanes on consecutive kk.
+template <int RB>
+__device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct, int m0, int cnt, float* smem, int* prow) {
+  constexpr int BK = 32, LS = BK + 4, BN = 128, WS = BN + 4, ROWS = 32 * RB;
+  constexpr int A_FLOATS = 128 * LS, STAGE = A_FLOATS + BK * WS;  // per stage: A rows [0, 128), then the W slab
+  const int c0 = ct * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  constexpr unsigned PAST = 0x80000000u, COL_PAST = 0x7FFF0000u;  // as in nt_panel_body
+  int* arow_off = prow;
+  int* yrow_off = prow + 128;
+  float* srow = reinterpret_cast<float*>(prow + 256);
+  if (tid < ROWS) {
+    unsigned ao = PAST, yo = PAST;
+    float sv = 0.f;
+    if (m0 + tid < cnt) {
+      const int pp = g.perm[g.offsets[e] + m0 + tid];
+      ao = (unsigned)((int64_t)(pp / g.a_div) * g.lda * 4);
+      yo = (unsigned)((int64_t)pp * g.Kd * 4);
+      sv = g.scale ? g.scale[pp] : 1.f;
+    }
+    arow_off[tid] = (int)ao;
+    yrow_off[tid] = (int)yo;
+    srow[tid] = sv;
+  }
+  __syncthreads();
+  // staging: A 8 threads per row (rows sr + 32 j, j < RB); W 32 threads per n row (rows wr + 8 j, j < 4)
+  const int sr = tid >> 3, sc = (tid & 7) * 4;
+  const int wr = tid >> 5, wc = (tid & 31) * 4;
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
+  const float* We = g.W + (int64_t)e * g.N * g.Kd;
+  const __amdgpu_buffer_rsrc_t w_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, (int)((int64_t)g.N * g.Kd * 4), 0x00020000);
+  constexpr int NS = RB + 4;
+  int goff[NS];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) goff[j] = arow_off[sr + 32 * j] + sc * 4;
+  // columns >= Kd: the whole thread reads past the buffer (zeros)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) goff[RB + j] = c0 + wc < g.Kd ? (int)(((int64_t)(wr + 8 * j) * g.Kd + c0 + wc) * 4) : (int)PAST;
+  const int wstep = g.Kd * 4;  // bytes per n row of W
+  float4 stg[NS];
+  auto gload = [&](int i, int k0) {
+    if (i < RB) stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, goff[i] + k0 * 4, 0, 0));
+    else stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, goff[i] + k0 * wstep, 0, 0));
+  };
+  auto lstore = [&](int i, float* stage) {
+    if (i < RB) st4(&stage[(sr + 32 * i) * LS + sc], stg[i]);
+    else st4(&stage[A_FLOATS + (wr + 8 * (i - RB)) * WS + wc], stg[i]);
+  };
+  const int nk = g.N / BK;
+  const int rot = (e * g.ncol + ct) % nk;
+  auto kof = [&](int kt) { int k = min(kt, nk - 1) + rot; k -= (k >= nk) ? nk : 0; return k * BK; };
+
+  f32x16 acc[RB];
+#pragma unroll
+  for (int j = 0; j < RB; ++j) acc[j] = zero16();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) gload(i, kof(0));
+#pragma unroll
+  for (int i = 0; i < NS; ++i) lstore(i, smem);
+#pragma unroll
+  for (int i = 0; i < NS; ++i) gload(i, kof(1));
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered in the state its back edge leaves
+  __syncthreads();
+  const int a_rd = ln * LS + 16 * hf, w_rd = A_FLOATS + (16 * hf) * WS + 32 * wave + ln;
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* cur = smem + (kt & 1) * STAGE;
+    float* nxt = smem + ((kt + 1) & 1) * STAGE;
+    const int k2 = kof(kt + 2);
+    float4 a[RB];
+    float b[4];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) a[j] = ld4(cur + a_rd + 32 * j * LS);
+#pragma unroll
+    for (int x = 0; x < 4; ++x) b[x] = cur[w_rd + x * WS];
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float4 an[RB];
+      float bn[4];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) an[j] = a[j];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) bn[x] = b[x];
+      if (s4 + 1 < 4) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) an[j] = ld4(cur + a_rd + 32 * j * LS + 4 * (s4 + 1));
+#pragma unroll
+        for (int x = 0; x < 4; ++x) bn[x] = cur[w_rd + (4 * (s4 + 1) + x) * WS];
+      }
+#pragma unroll
+      for (int i = s4 * NS / 4; i < (s4 + 1) * NS / 4; ++i) {
+        lstore(i, nxt);
+        gload(i, k2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) acc[j] = mfma32(f4(a[j], x), b[x], acc[j]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < RB; ++j) a[j] = an[j];
+#pragma unroll
+      for (int x = 0; x < 4; ++x) b[x] = bn[x];
+    }
+    __syncthreads();
+  }
+  const int c = c0 + 32 * wave + ln;
+  const unsigned coff = c < g.Kd ? (unsigned)c * 4u : COL_PAST;
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.Y, 0, (int)g.y_bytes, 0x00020000);
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = 32 * j + acc_row(r, hf);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] * srow[row]), y_rsrc, (int)((unsigned)yrow_off[row] + coff), 0, 0);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void grouped_nn_wide_kernel(GemmParams g) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * (128 * 36 + 32 * 132)];
+  __shared__ int prow[384];
+  int e, ct, m0, rb, cnt;
+  if (!find_unit_rb(g.offsets, g.E, g.ncol, g.slots, blockIdx.x, e, ct, m0, rb, cnt)) return;
+  e = __builtin_amdgcn_readfirstlane(e); ct = __builtin_amdgcn_readfirstlane(ct); m0 = __builtin_amdgcn_readfirstlane(m0);
+  rb = __builtin_amdgcn_readfirstlane(rb); cnt = __builtin_amdgcn_readfirstlane(cnt);
+  if (rb == 4) nn_panel_body<4>(g, e, ct, m0, cnt, smem, prow);
+  else if (rb == 3) nn_panel_body<3>(g, e, ct, m0, cnt, smem, prow);
+  else if (rb == 2) nn_panel_body<2>(g, e, ct, m0, cnt, smem, prow);
+  else nn_panel_body<1>(g, e, ct, m0, cnt, smem, prow);
+}
+
 // Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk]              tile: 64 pairs x 64*NB outputs
 template <int NB>
 __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
@@ -698,6 +836,186 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_kernel(GemmParams g) {
   }
 }
 
+// The weight gradient for the wide shapes (N, Kd >= 128) on the same pipeline: one workgroup owns a 128 (n) x 128
+// (kk) tile of one expert's dW and walks the expert's pairs 32 at a time; 2 x 2 waves of 64 x 64 (four accumulators
+// each), both operands read as columns of the staged slabs G[32 pairs][128 n] (scaled at the LDS store) and
+// X[32 pairs][128 kk] (the upper 16 pairs of a slab are stored rotated by 32 columns, so the two half-waves of a
+// ds_read_b32 use disjoint banks).  The source rows and scales of a step come from a four-deep ring of small LDS
+// tables that 32 threads fill three steps ahead from registers loaded one (scale) and two (perm) steps earlier:
+// no thread waits for a dependent load inside the pipeline, and no load sits behind a branch.
+__device__ __forceinline__ int div_by(int x, int d, int shift) { return shift >= 0 ? x >> shift : x / d; }
+
+template <bool HAS_SCALE>
+__global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g) {
+  constexpr int SS = 132, SLAB = 32 * SS, STAGE = 2 * SLAB;  // stage: G slab, X slab
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  __shared__ int tab_a[4][32], tab_x[4][32];
+  __shared__ float tab_s[4][32];
+  constexpr unsigned PAST = 0x80000000u, COL_PAST = 0x7FFF0000u;  // as in nt_panel_body
+  const int ntn = (g.N + 127) / 128, ntk = g.ncol;  // tiles along n, kk
+  const int u = xcd_remap(blockIdx.x, gridDim.x);
+  const int e = __builtin_amdgcn_readfirstlane(u / (ntn * ntk)), rem = u - e * ntn * ntk;
+  const int n0 = (rem / ntk) * 128, c0 = (rem % ntk) * 128;
+  const int beg = g.offsets[e], cnt = g.offsets[e + 1] - beg;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;  // wm: n half, wn: kk half
+  const int nstep = (cnt + 31) >> 5;
+
+  // every thread runs the table writers' loads (tid & 31 picks the pair; the range checks do the masking), only
+  // the first 32 write the tables
+  const __amdgpu_buffer_rsrc_t p_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(g.perm + beg), 0, cnt * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.scale, 0, HAS_SCALE ? (int)g.s_bytes : 0, 0x00020000);
+  auto pair_of = [&](int i) {  // pair id of the expert's i-th pair, -1 past its end
+    const int v = (int)__builtin_amdgcn_raw_buffer_load_b32(p_rsrc, i * 4, 0, 0);
+    return i < cnt ? v : -1;
+  };
+  auto scale_of = [&](int pp) {  // 0 for "no pair" (reads past the buffer)
+    if (HAS_SCALE) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(s_rsrc, pp >= 0 ? pp * 4 : (int)PAST, 0, 0));
+    return pp >= 0 ? 1.f : 0.f;
+  };
+  auto put = [&](int slot, int t, int pp, float sv) {
+    tab_a[slot][t] = pp >= 0 ? (int)((int64_t)div_by(pp, g.a_div, g.a_shift) * g.lda * 4) : (int)PAST;
+    tab_x[slot][t] = pp >= 0 ? (int)((int64_t)div_by(pp, g.b_div, g.b_shift) * g.ldb * 4) : (int)PAST;
+    tab_s[slot][t] = sv;
+  };
+  {  // steps 0, 1, 2
+    const int pp = pair_of(min(tid, 95));
+    const float sv = scale_of(pp);
+    if (tid < 96) put(tid >> 5, tid & 31, pp, sv);
+  }
+  // registers of the table writers: pair of step st + 3 with its scale, pair of step st + 4
+  int pv1 = pair_of(96 + (tid & 31));
+  float sv1 = scale_of(pv1);
+  int pv0 = pair_of(128 + (tid & 31));
+  __syncthreads();
+
+  // staging: 32 threads per slab row (16 B each); rows wr + 8 j (j < 4) of the G slab (slots 0..3) and the X slab (4..7)
+  const int wr = tid >> 5, wc = (tid & 31) * 4;
+  const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.B2, 0, (int)g.b_bytes, 0x00020000);
+  const unsigned gcol = n0 + wc < g.N ? (unsigned)(n0 + wc) * 4u : COL_PAST, xcol = c0 + wc < g.Kd ? (unsigned)(c0 + wc) * 4u : COL_PAST;
+  float4 stg[8];
+  float ssv[4];
+  auto gload = [&](int i, int step) {
+    const int slot = step & 3;
+    if (i < 4) {
+      stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)((unsigned)tab_a[slot][wr + 8 * i] + gcol), 0, 0));
+      ssv[i] = tab_s[slot][wr + 8 * i];
+    } else {
+      stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)((unsigned)tab_x[slot][wr + 8 * (i - 4)] + xcol), 0, 0));
+    }
+  };
+  auto lstore = [&](int i, float* stage) {  // rows 16..31 of a slab (i & 2): columns rotated by 32
+    const int col = (wc + 32 * ((i >> 1) & 1)) & 127;
+    if (i < 4) {
+      float4 t = stg[i];
+      const float sv = ssv[i];
+      t.x *= sv; t.y *= sv; t.z *= sv; t.w *= sv;
+      st4(&stage[(wr + 8 * i) * SS + col], t);
+    } else {
+      st4(&stage[SLAB + (wr + 8 * (i - 4)) * SS + col], stg[i]);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  float bsum[2] = {0.f, 0.f};
+  const bool want_bias = g.dbias && c0 == 0 && wn == 0;
+
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload(i, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lstore(i, smem);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload(i, 1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered in the state its back edge leaves
+  __syncthreads();
+  // this lane's columns in a slab: n (or kk) = 64 wm + ln and + 32, as stored for its half's 16 pairs
+  const int g_rd0 = (16 * hf) * SS + ((64 * wm + ln + 32 * hf) & 127), g_rd1 = (16 * hf) * SS + ((64 * wm + ln + 32 + 32 * hf) & 127);
+  const int x_rd0 = SLAB + (16 * hf) * SS + ((64 * wn + ln + 32 * hf) & 127), x_rd1 = SLAB + (16 * hf) * SS + ((64 * wn + ln + 32 + 32 * hf) & 127);
+  for (int st = 0; st < nstep; ++st) {
+    const float* cur = smem + (st & 1) * STAGE;
+    float* nxt = smem + ((st + 1) & 1) * STAGE;
+    // table of step st + 3 from the registers, then the loads that refill them (scale of st + 4's pairs, pairs of st + 5)
+    if (tid < 32) put((st + 3) & 3, tid, pv1, sv1);
+    pv1 = pv0;
+    sv1 = scale_of(pv1);
+    pv0 = pair_of(32 * (st + 5) + (tid & 31));
+    float a[2][4], b[2][4];
+    auto rd = [&](int q, float (&av)[2][4], float (&bv)[2][4]) {  // pairs 4 q .. 4 q + 3 of this half
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        av[0][x] = cur[g_rd0 + (4 * q + x) * SS];
+        av[1][x] = cur[g_rd1 + (4 * q + x) * SS];
+        bv[0][x] = cur[x_rd0 + (4 * q + x) * SS];
+        bv[1][x] = cur[x_rd1 + (4 * q + x) * SS];
+      }
+    };
+    rd(0, a, b);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float an[2][4], bn[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { an[i][x] = a[i][x]; bn[i][x] = b[i][x]; }
+      if (q + 1 < 4) rd(q + 1, an, bn);
+#pragma unroll
+      for (int i = 2 * q; i < 2 * q + 2; ++i) {
+        lstore(i, nxt);
+        gload(i, st + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+        acc[0][0] = mfma32(a[0][x], b[0][x], acc[0][0]);
+        acc[0][1] = mfma32(a[0][x], b[1][x], acc[0][1]);
+        acc[1][0] = mfma32(a[1][x], b[0][x], acc[1][0]);
+        acc[1][1] = mfma32(a[1][x], b[1][x], acc[1][1]);
+      }
+      if (want_bias) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { bsum[0] += a[0][x]; bsum[1] += a[1][x]; }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) { a[i][x] = an[i][x]; b[i][x] = bn[i][x]; }
+    }
+    __syncthreads();
+  }
+  // epilogue through the expert's slab of dW as a buffer: rows >= N fall past it, columns >= Kd carry COL_PAST
+  const __amdgpu_buffer_rsrc_t d_rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(g.Y + (int64_t)e * g.N * g.Kd), 0, (int)((int64_t)g.N * g.Kd * 4), 0x00020000);
+  const int row_bytes = g.Kd * 4;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const unsigned nbase = (unsigned)(n0 + 64 * wm + 32 * i + 4 * hf) * (unsigned)row_bytes;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + 64 * wn + 32 * j + ln;
+      const unsigned coff = c < g.Kd ? (unsigned)c * 4u : COL_PAST;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[i][j][r];  // (a copy: bit_cast of the vector-element lvalue itself reads element 0)
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d_rsrc,
+                                              (int)(nbase + (unsigned)(acc_row(r, 0) * row_bytes) + coff), 0, 0);
+      }
+    }
+  }
+  if (want_bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
+      const int n = n0 + 64 * wm + 32 * i + ln;
+      if (hf == 0 && n < g.N) g.dbias[(int64_t)e * g.N + n] = t;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // out[g, :] = sum_{o < outer} ( sum over the k slots of unit (g*outer+o), ascending expert id,
 //             of scale[p] * Y[p, :] )     -- the accumulation order of the reference loops.
@@ -843,8 +1161,13 @@ extern "C" int amk_grouped_gemm_nn(const float* A, int64_t lda, int a_div, const
   g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
   const unsigned mt = (unsigned)((P + 63) / 64 + E);
   AMK_CHECK_SUPPORTED((uint64_t)mt * ((Kd + 127) / 128) < (1ull << 31), "amk_grouped_gemm_nn: grid too large");
-  // same shape: NB 1 0.199 ms, NB 2 0.187 ms
-  if (Kd > 64) { g.ncol = (Kd + 127) / 128; hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+  g.a_bytes = ((P - 1) / a_div * lda + N) * 4;   // rows 0 .. (P-1)/a_div of A
+  g.y_bytes = P * Kd * 4;
+  if (Kd >= 128 && Kd % 4 == 0 && N % 32 == 0 && g.a_bytes < (1ll << 31) && g.y_bytes < 0x7FFF0000ll && (int64_t)N * Kd * 4 < (1ll << 31) &&
+      !getenv("AMK_MOE_NARROW")) {
+    g.ncol = (Kd + 127) / 128; g.slots = wg_slots();
+    hipLaunchKernelGGL(grouped_nn_wide_kernel, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  } else if (Kd > 64) { g.ncol = (Kd + 127) / 128; hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else { g.ncol = 1; hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH("amk_grouped_gemm_nn");
   return AMK_OK;
@@ -860,6 +1183,21 @@ extern "C" int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, co
   GemmParams g{};
   g.A = G; g.B2 = X; g.scale = scale; g.Y = dW; g.dbias = dbias; g.offsets = offsets; g.perm = perm;
   g.E = E; g.N = N; g.Kd = Kd; g.a_div = g_div; g.b_div = x_div; g.lda = ldg; g.ldb = ldx;
+  g.a_bytes = ((P - 1) / g_div * ldg + N) * 4;   // G buffer
+  g.b_bytes = ((P - 1) / x_div * ldx + Kd) * 4;  // X buffer
+  g.s_bytes = P * 4;
+  auto log2_of = [](int d) { int sft = 0; while ((1 << sft) < d) ++sft; return (1 << sft) == d ? sft : -1; };
+  g.a_shift = log2_of(g_div); g.b_shift = log2_of(x_div);
+  if (N >= 128 && Kd >= 128 && g.a_bytes < 0x7FFF0000ll && g.b_bytes < 0x7FFF0000ll && g.s_bytes < (1ll << 31) && (int64_t)N * Kd * 4 < 0x7FFF0000ll &&
+      !getenv("AMK_MOE_NARROW")) {
+    g.ncol = (Kd + 127) / 128;
+    const int64_t nwg = (int64_t)E * ((N + 127) / 128) * g.ncol;
+    AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_grouped_gemm_wgrad: grid too large");
+    if (scale) hipLaunchKernelGGL(grouped_wgrad_wide_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    else hipLaunchKernelGGL(grouped_wgrad_wide_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    AMK_CHECK_LAUNCH("amk_grouped_gemm_wgrad");
+    return AMK_OK;
+  }
   // same shape: NB 1 0.218 ms, NB 2 0.231 ms
   hipLaunchKernelGGL(grouped_wgrad_kernel<1>, dim3((Kd + 63) / 64, (N + 63) / 64, E), dim3(256), 0,
                      static_cast<hipStream_t>(stream), g);
