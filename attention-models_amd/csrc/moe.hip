@@ -845,17 +845,22 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_kernel(GemmParams g) {
 // no thread waits for a dependent load inside the pipeline, and no load sits behind a branch.
 __device__ __forceinline__ int div_by(int x, int d, int shift) { return shift >= 0 ? x >> shift : x / d; }
 
-template <bool HAS_SCALE>
+// TNB / TKB: 32-column blocks per wave along n / kk -- tile (64 TNB) x (64 TKB): (2, 2) for the square experts,
+// (1, 2) / (2, 1) for SwitchHead's (64 x D) and (D x 64) experts.
+template <bool HAS_SCALE, int TNB, int TKB>
 __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g) {
-  constexpr int SS = 132, SLAB = 32 * SS, STAGE = 2 * SLAB;  // stage: G slab, X slab
+  constexpr int WG_ = 64 * TNB, WX_ = 64 * TKB;       // slab widths (columns of G and of X in the tile)
+  constexpr int SG = WG_ + 4, SX = WX_ + 4;            // LDS row strides
+  constexpr int GSLAB = 32 * SG, STAGE = GSLAB + 32 * SX;
+  constexpr int NG = 2 * TNB, NX = 2 * TKB, NS = NG + NX;  // float4 per thread and step: G slots [0, NG), X slots [NG, NS)
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
   __shared__ int tab_a[4][32], tab_x[4][32];
   __shared__ float tab_s[4][32];
   constexpr unsigned PAST = 0x80000000u, COL_PAST = 0x7FFF0000u;  // as in nt_panel_body
-  const int ntn = (g.N + 127) / 128, ntk = g.ncol;  // tiles along n, kk
+  const int ntn = (g.N + WG_ - 1) / WG_, ntk = g.ncol;  // tiles along n, kk
   const int u = xcd_remap(blockIdx.x, gridDim.x);
   const int e = __builtin_amdgcn_readfirstlane(u / (ntn * ntk)), rem = u - e * ntn * ntk;
-  const int n0 = (rem / ntk) * 128, c0 = (rem % ntk) * 128;
+  const int n0 = (rem / ntk) * WG_, c0 = (rem % ntk) * WX_;
   const int beg = g.offsets[e], cnt = g.offsets[e + 1] - beg;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;  // wm: n half, wn: kk half
@@ -889,52 +894,61 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g
   int pv0 = pair_of(128 + (tid & 31));
   __syncthreads();
 
-  // staging: 32 threads per slab row (16 B each); rows wr + 8 j (j < 4) of the G slab (slots 0..3) and the X slab (4..7)
-  const int wr = tid >> 5, wc = (tid & 31) * 4;
+  // staging: 16 TNB (16 TKB) threads per G (X) slab row, 16 B each; G rows gr + (16 / TNB) j, X rows xr + (16 / TKB) j
+  const int gr = tid / (16 * TNB), gc = (tid % (16 * TNB)) * 4;
+  const int xr = tid / (16 * TKB), xc = (tid % (16 * TKB)) * 4;
   const __amdgpu_buffer_rsrc_t g_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.B2, 0, (int)g.b_bytes, 0x00020000);
-  const unsigned gcol = n0 + wc < g.N ? (unsigned)(n0 + wc) * 4u : COL_PAST, xcol = c0 + wc < g.Kd ? (unsigned)(c0 + wc) * 4u : COL_PAST;
-  float4 stg[8];
-  float ssv[4];
+  const unsigned gcol = n0 + gc < g.N ? (unsigned)(n0 + gc) * 4u : COL_PAST, xcol = c0 + xc < g.Kd ? (unsigned)(c0 + xc) * 4u : COL_PAST;
+  float4 stg[NS];
+  float ssv[NG];
   auto gload = [&](int i, int step) {
     const int slot = step & 3;
-    if (i < 4) {
-      stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)((unsigned)tab_a[slot][wr + 8 * i] + gcol), 0, 0));
-      ssv[i] = tab_s[slot][wr + 8 * i];
+    if (i < NG) {
+      const int row = gr + (16 / TNB) * i;
+      stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(g_rsrc, (int)((unsigned)tab_a[slot][row] + gcol), 0, 0));
+      ssv[i] = tab_s[slot][row];
     } else {
-      stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)((unsigned)tab_x[slot][wr + 8 * (i - 4)] + xcol), 0, 0));
+      const int row = xr + (16 / TKB) * (i - NG);
+      stg[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)((unsigned)tab_x[slot][row] + xcol), 0, 0));
     }
   };
-  auto lstore = [&](int i, float* stage) {  // rows 16..31 of a slab (i & 2): columns rotated by 32
-    const int col = (wc + 32 * ((i >> 1) & 1)) & 127;
-    if (i < 4) {
+  auto lstore = [&](int i, float* stage) {  // rows 16..31 of a slab (the second half of its slots): columns rotated by 32
+    if (i < NG) {
+      const int col = (gc + 32 * (i / TNB)) & (WG_ - 1);
       float4 t = stg[i];
       const float sv = ssv[i];
       t.x *= sv; t.y *= sv; t.z *= sv; t.w *= sv;
-      st4(&stage[(wr + 8 * i) * SS + col], t);
+      st4(&stage[(gr + (16 / TNB) * i) * SG + col], t);
     } else {
-      st4(&stage[SLAB + (wr + 8 * (i - 4)) * SS + col], stg[i]);
+      const int col = (xc + 32 * ((i - NG) / TKB)) & (WX_ - 1);
+      st4(&stage[GSLAB + (xr + (16 / TKB) * (i - NG)) * SX + col], stg[i]);
     }
   };
-  f32x16 acc[2][2];
+  f32x16 acc[TNB][TKB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TNB; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-  float bsum[2] = {0.f, 0.f};
+    for (int j = 0; j < TKB; ++j) acc[i][j] = zero16();
+  float bsum[TNB];
+#pragma unroll
+  for (int i = 0; i < TNB; ++i) bsum[i] = 0.f;
   const bool want_bias = g.dbias && c0 == 0 && wn == 0;
 
 #pragma unroll
-  for (int i = 0; i < 8; ++i) gload(i, 0);
+  for (int i = 0; i < NS; ++i) gload(i, 0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) lstore(i, smem);
+  for (int i = 0; i < NS; ++i) lstore(i, smem);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) gload(i, 1);
+  for (int i = 0; i < NS; ++i) gload(i, 1);
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered in the state its back edge leaves
   __syncthreads();
-  // this lane's columns in a slab: n (or kk) = 64 wm + ln and + 32, as stored for its half's 16 pairs
-  const int g_rd0 = (16 * hf) * SS + ((64 * wm + ln + 32 * hf) & 127), g_rd1 = (16 * hf) * SS + ((64 * wm + ln + 32 + 32 * hf) & 127);
-  const int x_rd0 = SLAB + (16 * hf) * SS + ((64 * wn + ln + 32 * hf) & 127), x_rd1 = SLAB + (16 * hf) * SS + ((64 * wn + ln + 32 + 32 * hf) & 127);
+  // this lane's columns in the slabs, as stored for its half's 16 pairs
+  int g_rd[TNB], x_rd[TKB];
+#pragma unroll
+  for (int i = 0; i < TNB; ++i) g_rd[i] = (16 * hf) * SG + ((32 * TNB * wm + 32 * i + ln + 32 * hf) & (WG_ - 1));
+#pragma unroll
+  for (int j = 0; j < TKB; ++j) x_rd[j] = GSLAB + (16 * hf) * SX + ((32 * TKB * wn + 32 * j + ln + 32 * hf) & (WX_ - 1));
   for (int st = 0; st < nstep; ++st) {
     const float* cur = smem + (st & 1) * STAGE;
     float* nxt = smem + ((st + 1) & 1) * STAGE;
@@ -943,47 +957,55 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g
     pv1 = pv0;
     sv1 = scale_of(pv1);
     pv0 = pair_of(32 * (st + 5) + (tid & 31));
-    float a[2][4], b[2][4];
-    auto rd = [&](int q, float (&av)[2][4], float (&bv)[2][4]) {  // pairs 4 q .. 4 q + 3 of this half
+    float a[TNB][4], b[TKB][4];
+    auto rd = [&](int q, float (&av)[TNB][4], float (&bv)[TKB][4]) {  // pairs 4 q .. 4 q + 3 of this half
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        av[0][x] = cur[g_rd0 + (4 * q + x) * SS];
-        av[1][x] = cur[g_rd1 + (4 * q + x) * SS];
-        bv[0][x] = cur[x_rd0 + (4 * q + x) * SS];
-        bv[1][x] = cur[x_rd1 + (4 * q + x) * SS];
+#pragma unroll
+        for (int i = 0; i < TNB; ++i) av[i][x] = cur[g_rd[i] + (4 * q + x) * SG];
+#pragma unroll
+        for (int j = 0; j < TKB; ++j) bv[j][x] = cur[x_rd[j] + (4 * q + x) * SX];
       }
     };
     rd(0, a, b);
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      float an[2][4], bn[2][4];
+      float an[TNB][4], bn[TKB][4];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int x = 0; x < 4; ++x) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { an[i][x] = a[i][x]; bn[i][x] = b[i][x]; }
+        for (int i = 0; i < TNB; ++i) an[i][x] = a[i][x];
+#pragma unroll
+        for (int j = 0; j < TKB; ++j) bn[j][x] = b[j][x];
+      }
       if (q + 1 < 4) rd(q + 1, an, bn);
 #pragma unroll
-      for (int i = 2 * q; i < 2 * q + 2; ++i) {
+      for (int i = q * NS / 4; i < (q + 1) * NS / 4; ++i) {
         lstore(i, nxt);
         gload(i, st + 2);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
-        acc[0][0] = mfma32(a[0][x], b[0][x], acc[0][0]);
-        acc[0][1] = mfma32(a[0][x], b[1][x], acc[0][1]);
-        acc[1][0] = mfma32(a[1][x], b[0][x], acc[1][0]);
-        acc[1][1] = mfma32(a[1][x], b[1][x], acc[1][1]);
+#pragma unroll
+        for (int i = 0; i < TNB; ++i)
+#pragma unroll
+          for (int j = 0; j < TKB; ++j) acc[i][j] = mfma32(a[i][x], b[j][x], acc[i][j]);
       }
       if (want_bias) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { bsum[0] += a[0][x]; bsum[1] += a[1][x]; }
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+          for (int i = 0; i < TNB; ++i) bsum[i] += a[i][x];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int x = 0; x < 4; ++x) {
 #pragma unroll
-        for (int x = 0; x < 4; ++x) { a[i][x] = an[i][x]; b[i][x] = bn[i][x]; }
+        for (int i = 0; i < TNB; ++i) a[i][x] = an[i][x];
+#pragma unroll
+        for (int j = 0; j < TKB; ++j) b[j][x] = bn[j][x];
+      }
     }
     __syncthreads();
   }
@@ -992,11 +1014,11 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g
       __builtin_amdgcn_make_buffer_rsrc((void*)(g.Y + (int64_t)e * g.N * g.Kd), 0, (int)((int64_t)g.N * g.Kd * 4), 0x00020000);
   const int row_bytes = g.Kd * 4;
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const unsigned nbase = (unsigned)(n0 + 64 * wm + 32 * i + 4 * hf) * (unsigned)row_bytes;
+  for (int i = 0; i < TNB; ++i) {
+    const unsigned nbase = (unsigned)(n0 + 32 * TNB * wm + 32 * i + 4 * hf) * (unsigned)row_bytes;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int c = c0 + 64 * wn + 32 * j + ln;
+    for (int j = 0; j < TKB; ++j) {
+      const int c = c0 + 32 * TKB * wn + 32 * j + ln;
       const unsigned coff = c < g.Kd ? (unsigned)c * 4u : COL_PAST;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -1008,9 +1030,9 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g
   }
   if (want_bias) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < TNB; ++i) {
       const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
-      const int n = n0 + 64 * wm + 32 * i + ln;
+      const int n = n0 + 32 * TNB * wm + 32 * i + ln;
       if (hf == 0 && n < g.N) g.dbias[(int64_t)e * g.N + n] = t;
     }
   }
@@ -1188,13 +1210,20 @@ extern "C" int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, co
   g.s_bytes = P * 4;
   auto log2_of = [](int d) { int sft = 0; while ((1 << sft) < d) ++sft; return (1 << sft) == d ? sft : -1; };
   g.a_shift = log2_of(g_div); g.b_shift = log2_of(x_div);
-  if (N >= 128 && Kd >= 128 && g.a_bytes < 0x7FFF0000ll && g.b_bytes < 0x7FFF0000ll && g.s_bytes < (1ll << 31) && (int64_t)N * Kd * 4 < 0x7FFF0000ll &&
-      !getenv("AMK_MOE_NARROW")) {
-    g.ncol = (Kd + 127) / 128;
-    const int64_t nwg = (int64_t)E * ((N + 127) / 128) * g.ncol;
+  if (N >= 64 && Kd >= 64 && N + Kd >= 192 && g.a_bytes < 0x7FFF0000ll && g.b_bytes < 0x7FFF0000ll && g.s_bytes < (1ll << 31) &&
+      (int64_t)N * Kd * 4 < 0x7FFF0000ll && !getenv("AMK_MOE_NARROW")) {
+    // tile 128 x 128; 64 x 128 / 128 x 64 for SwitchHead's (64 x D) / (D x 64) experts
+    const int tn = N >= 128 ? 128 : 64, tk = Kd >= 128 ? 128 : 64;
+    g.ncol = (Kd + tk - 1) / tk;
+    const int64_t nwg = (int64_t)E * ((N + tn - 1) / tn) * g.ncol;
     AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_grouped_gemm_wgrad: grid too large");
-    if (scale) hipLaunchKernelGGL(grouped_wgrad_wide_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, static_cast<hipStream_t>(stream), g);
-    else hipLaunchKernelGGL(grouped_wgrad_wide_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    const dim3 grid((unsigned)nwg), block(256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define AMK_WGRAD(S, TN_, TK_) hipLaunchKernelGGL((grouped_wgrad_wide_kernel<S, TN_, TK_>), grid, block, 0, st, g)
+    if (tn == 128 && tk == 128) { if (scale) AMK_WGRAD(true, 2, 2); else AMK_WGRAD(false, 2, 2); }
+    else if (tn == 64) { if (scale) AMK_WGRAD(true, 1, 2); else AMK_WGRAD(false, 1, 2); }
+    else { if (scale) AMK_WGRAD(true, 2, 1); else AMK_WGRAD(false, 2, 1); }
+#undef AMK_WGRAD
     AMK_CHECK_LAUNCH("amk_grouped_gemm_wgrad");
     return AMK_OK;
   }
