@@ -61,6 +61,8 @@ SIGNATURES = {
     "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 8),
     "amk_grouped_gemm_nt": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "amk_grouped_gemm_nn": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "amk_grouped_gemm_nt_acc": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _P]),
+    "amk_grouped_gemm_nn_acc": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _P]),
     "amk_grouped_gemm_wgrad": (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     "amk_moe_combine": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "amk_moe_gate_grad": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),

@@ -455,6 +455,21 @@ def moe_route(logits2, k):
     return dict(ids=ids, gate=gate, offsets=offsets, perm=perm)
 
 
+# Sums over the pairs of a row inside the expert GEMM (f32 atomics, amk_grouped_gemm_*_acc) instead of a (pairs, width)
+# intermediate and an ordered pass over it.  OFF by default: measured at the ViTMoE SwitchHead layer (16 pairs per row,
+# 68 M element adds) the atomics cost more than the 272 MB intermediate they remove -- output experts 0.237 ms against
+# 0.131 + 0.065 ms, V experts' input gradient 0.246 against 0.140 + 0.065 -- and the ordered combine keeps the
+# reference's accumulation order.  AMK_MOE_SUM_IN_GEMM=1 turns it on (never under the deterministic switches).
+MOE_SUM_IN_GEMM = os.environ.get("AMK_MOE_SUM_IN_GEMM", "0") == "1"
+
+
+def _moe_sum_in_gemm(width, depth, fan):
+    """width: output row length; depth: contraction length; fan: pairs per output row."""
+    if not MOE_SUM_IN_GEMM or DETERMINISTIC_ATTENTION_BACKWARD or torch.are_deterministic_algorithms_enabled():
+        return False
+    return fan >= 4 and width >= 128 and depth % 32 == 0
+
+
 class _RoutedLinear(torch.autograd.Function):
     """Top-k routed expert Linear + ordered combine, one launch per stage for ALL experts.
 
@@ -477,17 +492,27 @@ class _RoutedLinear(torch.autograd.Function):
         with _timed(f"moe_route U{U} E{E} k{k}"):
             r = moe_route(logits2.detach(), k)
         L = _lib.load()
-        Y = torch.empty((P, N), device=dev, dtype=torch.float32)
-        with _timed(f"grouped_nt P{P} N{N} K{Kd}"):
-            rc = L.amk_grouped_gemm_nt(_ptr(x2), Kd, x_div, _ptr(W), _ptr(bias), _ptr(r["offsets"]), _ptr(r["perm"]),
-                                       P, E, N, Kd, _ptr(Y), _stream())
-        _lib.check(rc, "amk_grouped_gemm_nt")
         G = U // outer
-        out = torch.empty((G, N), device=dev, dtype=torch.float32)
-        with _timed(f"moe_combine G{G} N{N} x{outer * k}"):
-            rc = L.amk_moe_combine(_ptr(Y), _ptr(r["ids"]), _ptr(r["gate"]) if weighted else _NULL, G, outer, k, N,
-                                   _ptr(out), _stream())
-        _lib.check(rc, "amk_moe_combine")
+        if not weighted and _moe_sum_in_gemm(N, Kd, outer * k):
+            # un-weighted sum over the pairs of an output row (SwitchHead's output experts): folded into the GEMM's
+            # epilogue -- the (P, N) per-pair intermediate (272 MB at the ViTMoE layer) is never written
+            Y = None
+            out = torch.zeros((G, N), device=dev, dtype=torch.float32)
+            with _timed(f"grouped_nt_acc P{P} N{N} K{Kd}"):
+                rc = L.amk_grouped_gemm_nt_acc(_ptr(x2), Kd, x_div, _ptr(W), _ptr(bias), _ptr(r["offsets"]), _ptr(r["perm"]),
+                                               P, E, N, Kd, _ptr(out), outer * k, _stream())
+            _lib.check(rc, "amk_grouped_gemm_nt_acc")
+        else:
+            Y = torch.empty((P, N), device=dev, dtype=torch.float32)
+            with _timed(f"grouped_nt P{P} N{N} K{Kd}"):
+                rc = L.amk_grouped_gemm_nt(_ptr(x2), Kd, x_div, _ptr(W), _ptr(bias), _ptr(r["offsets"]), _ptr(r["perm"]),
+                                           P, E, N, Kd, _ptr(Y), _stream())
+            _lib.check(rc, "amk_grouped_gemm_nt")
+            out = torch.empty((G, N), device=dev, dtype=torch.float32)
+            with _timed(f"moe_combine G{G} N{N} x{outer * k}"):
+                rc = L.amk_moe_combine(_ptr(Y), _ptr(r["ids"]), _ptr(r["gate"]) if weighted else _NULL, G, outer, k, N,
+                                       _ptr(out), _stream())
+            _lib.check(rc, "amk_moe_combine")
         ctx.save_for_backward(x2, W, Y, r["ids"], r["gate"], r["offsets"], r["perm"])
         ctx.cfg = (k, x_div, weighted, outer, E, bias is not None)
         ctx.mark_non_differentiable(r["ids"])
@@ -510,14 +535,22 @@ class _RoutedLinear(torch.autograd.Function):
             dlogits = torch.empty((U, E), device=dev, dtype=torch.float32)
             rc = L.amk_moe_gate_grad(_ptr(d_out), _ptr(Y), _ptr(ids), _ptr(gate), P, k, E, N, g_div, _ptr(dlogits), _stream())
             _lib.check(rc, "amk_moe_gate_grad")
-        dxp = torch.empty((P, Kd), device=dev, dtype=torch.float32)
-        with _timed(f"grouped_nn P{P} N{N} K{Kd}"):
-            rc = L.amk_grouped_gemm_nn(_ptr(d_out), N, g_div, _ptr(W), scale, _ptr(offsets), _ptr(perm), P, E, N, Kd,
-                                       _ptr(dxp), _stream())
-        _lib.check(rc, "amk_grouped_gemm_nn")
-        dx = torch.empty_like(x2)
-        rc = L.amk_moe_combine(_ptr(dxp), _ptr(ids), _NULL, x2.shape[0], x_div // k, k, Kd, _ptr(dx), _stream())
-        _lib.check(rc, "amk_moe_combine")
+        if _moe_sum_in_gemm(Kd, N, x_div):
+            # the input rows' gradients are sums over the x_div pairs that read them: folded into the GEMM's epilogue
+            dx = torch.zeros_like(x2)
+            with _timed(f"grouped_nn_acc P{P} N{N} K{Kd}"):
+                rc = L.amk_grouped_gemm_nn_acc(_ptr(d_out), N, g_div, _ptr(W), scale, _ptr(offsets), _ptr(perm), P, E, N, Kd,
+                                               _ptr(dx), x_div, _stream())
+            _lib.check(rc, "amk_grouped_gemm_nn_acc")
+        else:
+            dxp = torch.empty((P, Kd), device=dev, dtype=torch.float32)
+            with _timed(f"grouped_nn P{P} N{N} K{Kd}"):
+                rc = L.amk_grouped_gemm_nn(_ptr(d_out), N, g_div, _ptr(W), scale, _ptr(offsets), _ptr(perm), P, E, N, Kd,
+                                           _ptr(dxp), _stream())
+            _lib.check(rc, "amk_grouped_gemm_nn")
+            dx = torch.empty_like(x2)
+            rc = L.amk_moe_combine(_ptr(dxp), _ptr(ids), _NULL, x2.shape[0], x_div // k, k, Kd, _ptr(dx), _stream())
+            _lib.check(rc, "amk_moe_combine")
         dW = torch.empty_like(W)
         db = torch.empty((E, N), device=dev, dtype=torch.float32) if has_bias else None
         with _timed(f"grouped_wgrad P{P} N{N} K{Kd}"):

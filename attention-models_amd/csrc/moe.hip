@@ -194,6 +194,7 @@ struct GemmParams {
   int64_t y_bytes;       // size of the Y buffer (wide kernels)
   int64_t b_bytes, s_bytes;  // wgrad: sizes of the X and scale buffers
   int a_shift, b_shift;  // log2 of a_div / b_div when they are powers of two, else -1
+  int y_div;             // wide nt / nn: > 0 = accumulate mode, pair p ADDS into output row p / y_div (f32 atomics)
 };
 
 // Locate this workgroup's unit = (expert, output tile, 64-pair row tile).  The grid is 1-D over the units in
@@ -398,7 +399,7 @@ __device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct
     if (m0 + tid < cnt) {
       const int pp = g.perm[g.offsets[e] + m0 + tid];
       ao = (unsigned)((int64_t)(pp / g.a_div) * g.lda * 4);
-      yo = (unsigned)((int64_t)pp * g.N * 4);
+      yo = (unsigned)((int64_t)(g.y_div > 0 ? pp / g.y_div : pp) * g.N * 4);
     }
     arow_off[tid] = (int)ao;
     yrow_off[tid] = (int)yo;
@@ -494,7 +495,8 @@ __device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const unsigned yo = (unsigned)yrow_off[32 * j + acc_row(r, hf)];
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] + bv), y_rsrc, (int)(yo + coff), 0, 0);
+      if (g.y_div > 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[j][r] + bv, y_rsrc, (int)(yo + coff), 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] + bv), y_rsrc, (int)(yo + coff), 0, 0);
     }
   }
 }
@@ -533,7 +535,7 @@ __device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct
     if (m0 + tid < cnt) {
       const int pp = g.perm[g.offsets[e] + m0 + tid];
       ao = (unsigned)((int64_t)(pp / g.a_div) * g.lda * 4);
-      yo = (unsigned)((int64_t)pp * g.Kd * 4);
+      yo = (unsigned)((int64_t)(g.y_div > 0 ? pp / g.y_div : pp) * g.Kd * 4);
       sv = g.scale ? g.scale[pp] : 1.f;
     }
     arow_off[tid] = (int)ao;
@@ -632,7 +634,8 @@ __device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = 32 * j + acc_row(r, hf);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] * srow[row]), y_rsrc, (int)((unsigned)yrow_off[row] + coff), 0, 0);
+      if (g.y_div > 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[j][r] * srow[row], y_rsrc, (int)((unsigned)yrow_off[row] + coff), 0, 0);
+      else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] * srow[row]), y_rsrc, (int)((unsigned)yrow_off[row] + coff), 0, 0);
     }
   }
 }
@@ -1151,48 +1154,76 @@ static int check_gemm(const char* who, const void* A, const void* W, const void*
   return AMK_OK;
 }
 
-extern "C" int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const float* W, const float* bias,
-                                   const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
-                                   float* Y, void* stream) {
-  const int rc = check_gemm("amk_grouped_gemm_nt", A, W, Y, offsets, perm, P, E, N, Kd, a_div, lda);
+static int grouped_nt_impl(const char* who, const float* A, int64_t lda, int a_div, const float* W, const float* bias,
+                           const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                           float* Y, int y_div, void* stream) {
+  const int rc = check_gemm(who, A, W, Y, offsets, perm, P, E, N, Kd, a_div, lda);
   if (rc) return rc;
   GemmParams g{};
   g.A = A; g.W = W; g.bias = bias; g.Y = Y; g.offsets = offsets; g.perm = perm;
-  g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
+  g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda; g.y_div = y_div;
   const unsigned mt = (unsigned)((P + 63) / 64 + E);
-  AMK_CHECK_SUPPORTED((uint64_t)mt * ((N + 63) / 64) < (1ull << 31), "amk_grouped_gemm_nt: grid too large");
-  // measured at the ViTMoE layer shape (P 8320, N = Kd = 1024, E 32): NB 1 0.207 ms, NB 2 0.240 ms
+  AMK_CHECK_SUPPORTED((uint64_t)mt * ((N + 63) / 64) < (1ull << 31), "%s: grid too large", who);
   g.a_bytes = ((P - 1) / a_div * lda + Kd) * 4;   // rows 0 .. (P-1)/a_div of A
-  g.y_bytes = P * N * 4;
-  if (N >= 128 && Kd % 32 == 0 && g.a_bytes < (1ll << 31) && g.y_bytes < 0x7FFF0000ll && (int64_t)N * Kd * 4 < (1ll << 31) && !getenv("AMK_MOE_NARROW"))
+  g.y_bytes = (y_div > 0 ? (P - 1) / y_div + 1 : P) * N * 4;
+  const bool wide = N >= 128 && Kd % 32 == 0 && g.a_bytes < (1ll << 31) && g.y_bytes < 0x7FFF0000ll && (int64_t)N * Kd * 4 < (1ll << 31);
+  AMK_CHECK_SUPPORTED(y_div == 0 || wide, "%s: the accumulating form needs N >= 128, Kd %% 32 == 0 and buffers below 2 GB", who);
+  if (wide && (y_div > 0 || !getenv("AMK_MOE_NARROW")))
     { g.ncol = (N + 127) / 128; g.slots = wg_slots();  // grid: the bound for two-block tiles; the surplus workgroups leave at once
       hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3((unsigned)((P + 63) / 64 + E) * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else
     { g.ncol = (N + 63) / 64; hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
-  AMK_CHECK_LAUNCH("amk_grouped_gemm_nt");
+  AMK_CHECK_LAUNCH(who);
+  return AMK_OK;
+}
+
+extern "C" int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const float* W, const float* bias,
+                                   const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                                   float* Y, void* stream) {
+  return grouped_nt_impl("amk_grouped_gemm_nt", A, lda, a_div, W, bias, offsets, perm, P, E, N, Kd, Y, 0, stream);
+}
+
+extern "C" int amk_grouped_gemm_nt_acc(const float* A, int64_t lda, int a_div, const float* W, const float* bias,
+                                       const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                                       float* Y, int y_div, void* stream) {
+  AMK_CHECK_ARG(y_div > 0, "amk_grouped_gemm_nt_acc: y_div must be positive");
+  return grouped_nt_impl("amk_grouped_gemm_nt_acc", A, lda, a_div, W, bias, offsets, perm, P, E, N, Kd, Y, y_div, stream);
+}
+
+static int grouped_nn_impl(const char* who, const float* A, int64_t lda, int a_div, const float* W, const float* scale,
+                           const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                           float* Y, int y_div, void* stream) {
+  const int rc = check_gemm(who, A, W, Y, offsets, perm, P, E, N, Kd, a_div, lda);
+  if (rc) return rc;
+  GemmParams g{};
+  g.A = A; g.W = W; g.scale = scale; g.Y = Y; g.offsets = offsets; g.perm = perm;
+  g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda; g.y_div = y_div;
+  const unsigned mt = (unsigned)((P + 63) / 64 + E);
+  AMK_CHECK_SUPPORTED((uint64_t)mt * ((Kd + 127) / 128) < (1ull << 31), "%s: grid too large", who);
+  g.a_bytes = ((P - 1) / a_div * lda + N) * 4;   // rows 0 .. (P-1)/a_div of A
+  g.y_bytes = (y_div > 0 ? (P - 1) / y_div + 1 : P) * Kd * 4;
+  const bool wide = Kd >= 128 && Kd % 4 == 0 && N % 32 == 0 && g.a_bytes < (1ll << 31) && g.y_bytes < 0x7FFF0000ll && (int64_t)N * Kd * 4 < (1ll << 31);
+  AMK_CHECK_SUPPORTED(y_div == 0 || wide, "%s: the accumulating form needs Kd >= 128, N %% 32 == 0 and buffers below 2 GB", who);
+  if (wide && (y_div > 0 || !getenv("AMK_MOE_NARROW"))) {
+    g.ncol = (Kd + 127) / 128; g.slots = wg_slots();
+    hipLaunchKernelGGL(grouped_nn_wide_kernel, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  } else if (Kd > 64) { g.ncol = (Kd + 127) / 128; hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+  else { g.ncol = 1; hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+  AMK_CHECK_LAUNCH(who);
   return AMK_OK;
 }
 
 extern "C" int amk_grouped_gemm_nn(const float* A, int64_t lda, int a_div, const float* W, const float* scale,
                                    const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
                                    float* Y, void* stream) {
-  const int rc = check_gemm("amk_grouped_gemm_nn", A, W, Y, offsets, perm, P, E, N, Kd, a_div, lda);
-  if (rc) return rc;
-  GemmParams g{};
-  g.A = A; g.W = W; g.scale = scale; g.Y = Y; g.offsets = offsets; g.perm = perm;
-  g.E = E; g.N = N; g.Kd = Kd; g.a_div = a_div; g.b_div = 1; g.lda = lda;
-  const unsigned mt = (unsigned)((P + 63) / 64 + E);
-  AMK_CHECK_SUPPORTED((uint64_t)mt * ((Kd + 127) / 128) < (1ull << 31), "amk_grouped_gemm_nn: grid too large");
-  g.a_bytes = ((P - 1) / a_div * lda + N) * 4;   // rows 0 .. (P-1)/a_div of A
-  g.y_bytes = P * Kd * 4;
-  if (Kd >= 128 && Kd % 4 == 0 && N % 32 == 0 && g.a_bytes < (1ll << 31) && g.y_bytes < 0x7FFF0000ll && (int64_t)N * Kd * 4 < (1ll << 31) &&
-      !getenv("AMK_MOE_NARROW")) {
-    g.ncol = (Kd + 127) / 128; g.slots = wg_slots();
-    hipLaunchKernelGGL(grouped_nn_wide_kernel, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g);
-  } else if (Kd > 64) { g.ncol = (Kd + 127) / 128; hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
-  else { g.ncol = 1; hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
-  AMK_CHECK_LAUNCH("amk_grouped_gemm_nn");
-  return AMK_OK;
+  return grouped_nn_impl("amk_grouped_gemm_nn", A, lda, a_div, W, scale, offsets, perm, P, E, N, Kd, Y, 0, stream);
+}
+
+extern "C" int amk_grouped_gemm_nn_acc(const float* A, int64_t lda, int a_div, const float* W, const float* scale,
+                                       const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                                       float* Y, int y_div, void* stream) {
+  AMK_CHECK_ARG(y_div > 0, "amk_grouped_gemm_nn_acc: y_div must be positive");
+  return grouped_nn_impl("amk_grouped_gemm_nn_acc", A, lda, a_div, W, scale, offsets, perm, P, E, N, Kd, Y, y_div, stream);
 }
 
 extern "C" int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, const float* X, int64_t ldx, int x_div,

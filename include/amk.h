@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 120 /* 0.2.0: kept attention scores (amk_attn_fwd_keep / amk_attn_bwd_kept), 256-key backward workgroups */
+#define AMK_VERSION 121 /* 0.2.0: kept attention scores (amk_attn_fwd_keep / amk_attn_bwd_kept), 256-key backward workgroups */
 
 enum {
   AMK_OK = 0,
@@ -245,6 +245,21 @@ int amk_grouped_gemm_nt(const float* A, int64_t lda, int a_div, const float* W, 
 int amk_grouped_gemm_nn(const float* A, int64_t lda, int a_div, const float* W, const float* scale,
                         const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
                         float* Y, void* stream);
+
+/* The same two products with the sum over the pairs of an output row folded in: pair p ADDS its row into
+ * Y[p / y_div, :] (f32 atomics; Y is ((P-1)/y_div + 1, N) resp. (.., Kd) and must be ZEROED by the caller).
+ * Replaces amk_grouped_gemm_* followed by amk_moe_combine where the combine is un-weighted -- the head / slot sum
+ * of SwitchHead's output experts (switchhead_attention.py:86-87,115: 16 pairs per token, a 272 MB per-pair
+ * intermediate at the ViTMoE layer size) and the sum of the input gradients of its V experts -- at the price of
+ * the reference's fixed accumulation order (ascending expert id): sums differ in the last bits from run to run.
+ * Needs the wide kernels: N >= 128 and Kd % 32 == 0 (nt), Kd >= 128 and N % 32 == 0 (nn), buffers below 2 GB;
+ * AMK_EUNSUPPORTED otherwise. */
+int amk_grouped_gemm_nt_acc(const float* A, int64_t lda, int a_div, const float* W, const float* bias,
+                            const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                            float* Y, int y_div, void* stream);
+int amk_grouped_gemm_nn_acc(const float* A, int64_t lda, int a_div, const float* W, const float* scale,
+                            const int32_t* offsets, const int32_t* perm, int64_t P, int E, int N, int Kd,
+                            float* Y, int y_div, void* stream);
 
 /* dW[e] = sum_{p in e} scale[p] * G[p / g_div, :]^T (x) X[p / x_div, :]   (E,N,Kd), fully
  * overwritten; dbias[e] = sum_{p in e} scale[p] * G[p / g_div, :] (E,N) or NULL. */

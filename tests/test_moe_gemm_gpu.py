@@ -77,6 +77,23 @@ def test_grouped_gemms_vs_pair_loop(device, case):
     want = torch.stack([sc[p] * (Gc[p // a_div] @ Wc[int(ids[p])]) for p in range(P)])
     close(Y2, want, "grouped_nn")
 
+    # the accumulating forms: pair p adds into row p / y_div of a zeroed output (wide shapes only)
+    for y_div in (k, 4 * k):
+        if N >= 128 and Kd % 32 == 0:
+            Ya = torch.zeros(((P - 1) // y_div + 1, N), device=dev)
+            L_.check(L.amk_grouped_gemm_nt_acc(ptr(A), Kd, a_div, ptr(W), ptr(bias), ptr(r["offsets"]), ptr(r["perm"]), P, E, N, Kd,
+                                               ptr(Ya), y_div, st), "amk_grouped_gemm_nt_acc")
+            want_a = torch.zeros(Ya.shape, dtype=torch.float64)
+            want_a.index_add_(0, torch.arange(P) // y_div, torch.stack([Ac[p // a_div] @ Wc[int(ids[p])].t() + bc[int(ids[p])] for p in range(P)]))
+            close(Ya, want_a, f"grouped_nt_acc y_div={y_div}")
+        if Kd >= 128 and N % 32 == 0:
+            Yb = torch.zeros(((P - 1) // y_div + 1, Kd), device=dev)
+            L_.check(L.amk_grouped_gemm_nn_acc(ptr(Gm), N, a_div, ptr(W), ptr(scale), ptr(r["offsets"]), ptr(r["perm"]), P, E, N, Kd,
+                                               ptr(Yb), y_div, st), "amk_grouped_gemm_nn_acc")
+            want_b2 = torch.zeros(Yb.shape, dtype=torch.float64)
+            want_b2.index_add_(0, torch.arange(P) // y_div, want)
+            close(Yb, want_b2, f"grouped_nn_acc y_div={y_div}")
+
     # weight gradient (with and without the scale)
     for use_scale in (True, False):
         dW = torch.full((E, N, Kd), float("nan"), device=dev)
