@@ -43,27 +43,30 @@ __device__ __forceinline__ f32x16 zero16() {
 constexpr int MAX_K = 8;
 
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict__ logits, int64_t U, int E, int k,
+template <int KK>
+__global__ __launch_bounds__(128) void route_topk_kernel(const float* __restrict__ logits, int64_t U, int E,
                                                          int64_t* __restrict__ ids, float* __restrict__ gate) {
-  // A block takes 256 consecutive units = 256*E CONTIGUOUS logits; they are staged through LDS in
+  // A block takes 128 consecutive units = 128*E CONTIGUOUS logits; they are staged through LDS in
   // chunks of 32 experts by coalesced loads (consecutive threads read consecutive floats of a unit's
   // row; a thread reading its own row directly would touch 64 rows per instruction), then every thread
   // merges its unit's 32 values into a sorted top-k list: descending value, lowest index on ties --
-  // the order torch.topk gives on distinct values.
-  constexpr int EC = 32;
-  __shared__ float tile[256 * (EC + 1)];
+  // the order torch.topk gives on distinct values.  k is a template parameter: the list lives in KK
+  // registers and an insertion is KK compares (with a run-time k and an 8-entry list the kernel was 21 us
+  // for the 33280 units of a SwitchHead layer).
+  constexpr int EC = 32, UB = 128;
+  __shared__ float tile[UB * (EC + 1)];
   const int tid = threadIdx.x;
-  const int64_t u0 = (int64_t)blockIdx.x * 256;
+  const int64_t u0 = (int64_t)blockIdx.x * UB;
   const int64_t u = u0 + tid;
-  float bv[MAX_K];
-  int bi[MAX_K];
+  float bv[KK];
+  int bi[KK];
 #pragma unroll
-  for (int s = 0; s < MAX_K; ++s) { bv[s] = -INFINITY; bi[s] = -1; }
-  const int nu = (int)min((int64_t)256, U - u0);
+  for (int s = 0; s < KK; ++s) { bv[s] = -INFINITY; bi[s] = -1; }
+  const int nu = (int)min((int64_t)UB, U - u0);
   for (int e0 = 0; e0 < E; e0 += EC) {
     const int ne = min(EC, E - e0);
     __syncthreads();
-    for (int f = tid; f < nu * ne; f += 256) {  // f -> (unit f / ne, expert f % ne): ne consecutive floats per row
+    for (int f = tid; f < nu * ne; f += UB) {  // f -> (unit f / ne, expert f % ne): ne consecutive floats per row
       const int r = f / ne, c = f % ne;
       tile[r * (EC + 1) + c] = logits[(u0 + r) * E + e0 + c];
     }
@@ -72,14 +75,14 @@ __global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict
       for (int c = 0; c < ne; ++c) {
         const float v = tile[tid * (EC + 1) + c];
         // insert (v, e0 + c) behind every entry with value >= v (equal values: the earlier index stays first)
-        if (bi[k - 1] < 0 || v > bv[k - 1]) {
-          int pos = k - 1;
+        if (bi[KK - 1] < 0 || v > bv[KK - 1]) {
+          int pos = KK - 1;
 #pragma unroll
-          for (int s = MAX_K - 2; s >= 0; --s) {
-            if (s < k - 1 && (bi[s] < 0 || v > bv[s])) { bv[s + 1] = bv[s]; bi[s + 1] = bi[s]; pos = s; }
+          for (int s = KK - 2; s >= 0; --s) {
+            if (bi[s] < 0 || v > bv[s]) { bv[s + 1] = bv[s]; bi[s + 1] = bi[s]; pos = s; }
           }
 #pragma unroll
-          for (int s = 0; s < MAX_K; ++s)
+          for (int s = 0; s < KK; ++s)
             if (s == pos) { bv[s] = v; bi[s] = e0 + c; }
         }
       }
@@ -87,39 +90,55 @@ __global__ __launch_bounds__(256) void route_topk_kernel(const float* __restrict
   }
   if (u < U) {
 #pragma unroll
-    for (int s = 0; s < MAX_K; ++s)
-      if (s < k) {
-        ids[u * k + s] = bi[s];
-        gate[u * k + s] = 1.f / (1.f + expf(-bv[s]));
-      }
+    for (int s = 0; s < KK; ++s) {
+      ids[u * KK + s] = bi[s];
+      gate[u * KK + s] = 1.f / (1.f + expf(-bv[s]));
+    }
   }
 }
 
 // Deterministic expert-major ordering in three small launches (no serial scan over the pairs):
-//   route_local : a block takes 256 consecutive pairs; rank of a pair among the EARLIER pairs of the
+//   route_local : a block takes 1024 consecutive pairs; rank of a pair among the EARLIER pairs of the
 //                 same expert inside the block (LDS broadcast compare loop) + the block's histogram.
 //   route_scan  : per expert, exclusive scan of the block histograms -> block bases, counts, offsets.
 //   route_perm  : perm[offsets[e] + base[block][e] + local rank] = pair.
 // Pairs of one expert therefore appear in ascending pair order, whatever the launch timing.
-__global__ __launch_bounds__(256) void route_local_kernel(const int64_t* __restrict__ ids, int64_t P, int E,
-                                                          int32_t* __restrict__ rank, int32_t* __restrict__ blockhist) {
-  __shared__ int sid[256];
-  const int tid = threadIdx.x;
-  const int64_t p = (int64_t)blockIdx.x * 256 + tid;
+constexpr int ROUTE_BLOCK = 1024;  // pairs per block of route_local / route_perm (16 waves): 65 blocks at a SwitchHead layer
+
+__global__ __launch_bounds__(ROUTE_BLOCK) void route_local_kernel(const int64_t* __restrict__ ids, int64_t P, int E,
+                                                                 int32_t* __restrict__ rank, int32_t* __restrict__ blockhist) {
+  // inside a wave: one ballot per DISTINCT expert present (at most min(E, 64) rounds) gives every lane the set of
+  // lanes with its expert -- rank among the earlier ones = popcount below the lane; across the sixteen waves the
+  // per-wave counts go through LDS.  (A compare loop over the pairs of a 256-pair block was 8 us per launch, and
+  // 260 blocks made the scan kernel's walk long.)
+  constexpr int NW = ROUTE_BLOCK / 64;
+  extern __shared__ int wcount[];  // [NW][E]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t p = (int64_t)blockIdx.x * ROUTE_BLOCK + tid;
   const int my = (p < P) ? (int)ids[p] : -1;
-  sid[tid] = my;
+  for (int i = tid; i < NW * E; i += ROUTE_BLOCK) wcount[i] = 0;
   __syncthreads();
-  int r = 0;
-  for (int j = 0; j < tid; ++j) r += (sid[j] == my);
-  if (p < P) rank[p] = r;
-  // histogram: the LAST pair of each expert in the block knows the count (its rank + 1)
-  int32_t* bh = blockhist + (int64_t)blockIdx.x * E;
-  for (int e = tid; e < E; e += 256) bh[e] = 0;
+  unsigned long long remaining = __ballot(my >= 0), mine = 0;
+  while (remaining) {
+    const int leader = __builtin_ctzll(remaining);
+    const int el = __shfl(my, leader, 64);
+    const unsigned long long same = __ballot(my == el);
+    if (my == el) mine = same;
+    if (lane == leader) wcount[wave * E + el] = __builtin_popcountll(same);
+    remaining &= ~same;
+  }
   __syncthreads();
   if (my >= 0) {
-    bool last = true;
-    for (int j = tid + 1; j < 256; ++j) last &= (sid[j] != my);
-    if (last) bh[my] = r + 1;
+    int r = __builtin_popcountll(mine & ((1ull << lane) - 1ull));
+    for (int w = 0; w < wave; ++w) r += wcount[w * E + my];
+    rank[p] = r;
+  }
+  int32_t* bh = blockhist + (int64_t)blockIdx.x * E;
+  for (int e = tid; e < E; e += ROUTE_BLOCK) {
+    int c = 0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) c += wcount[w * E + e];
+    bh[e] = c;
   }
 }
 
@@ -171,7 +190,7 @@ __global__ __launch_bounds__(256) void route_perm_kernel(const int64_t* __restri
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const int e = (int)ids[p];
-  perm[offsets[e] + blockbase[(int64_t)blockIdx.x * E + e] + rank[p]] = (int)p;
+  perm[offsets[e] + blockbase[(p / ROUTE_BLOCK) * E + e] + rank[p]] = (int)p;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1133,11 +1152,21 @@ extern "C" int amk_moe_route(const float* logits, int64_t U, int E, int k,
   const int64_t P = U * k;
   AMK_CHECK_SUPPORTED(P < (1ll << 31), "amk_moe_route: too many routed pairs");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipLaunchKernelGGL(route_topk_kernel, dim3((unsigned)((U + 255) / 256)), dim3(256), 0, st, logits, U, E, k, ids, gate);
-  const int nblk = (int)((P + 255) / 256);
-  hipLaunchKernelGGL(route_local_kernel, dim3(nblk), dim3(256), 0, st, ids, P, E, rank, blockhist);
+  const dim3 tgrid((unsigned)((U + 127) / 128)), tblock(128);
+  switch (k) {
+    case 1: hipLaunchKernelGGL(route_topk_kernel<1>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
+    case 2: hipLaunchKernelGGL(route_topk_kernel<2>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
+    case 3: hipLaunchKernelGGL(route_topk_kernel<3>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
+    case 4: hipLaunchKernelGGL(route_topk_kernel<4>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
+    case 5: hipLaunchKernelGGL(route_topk_kernel<5>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
+    case 6: hipLaunchKernelGGL(route_topk_kernel<6>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
+    case 7: hipLaunchKernelGGL(route_topk_kernel<7>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
+    default: hipLaunchKernelGGL(route_topk_kernel<8>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
+  }
+  const int nblk = (int)((P + ROUTE_BLOCK - 1) / ROUTE_BLOCK);
+  hipLaunchKernelGGL(route_local_kernel, dim3(nblk), dim3(ROUTE_BLOCK), (size_t)(ROUTE_BLOCK / 64) * E * sizeof(int), st, ids, P, E, rank, blockhist);
   hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, st, blockhist, nblk, E, counts, offsets);
-  hipLaunchKernelGGL(route_perm_kernel, dim3(nblk), dim3(256), 0, st, ids, offsets, blockhist, rank, P, E, perm);
+  hipLaunchKernelGGL(route_perm_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, st, ids, offsets, blockhist, rank, P, E, perm);
   AMK_CHECK_LAUNCH("amk_moe_route");
   return AMK_OK;
 }
