@@ -353,8 +353,10 @@ __device__ __forceinline__ int wave_sum(int v) {
 // launch then fill the `slots` workgroup slots of the chip in few, long rounds (768 units of 3 blocks on 512
 // slots take two rounds of which the second is half empty); every wave evaluates
 //   rounds(m) x (mean blocks per unit + 0.35)      [0.35 blocks: a unit's fixed cost]
-// for the four m from the same offsets and takes the smallest (ties: the taller tile).
-__device__ __forceinline__ bool find_unit_rb(const int32_t* offsets, int E, int ncol, int slots, int bid, int& e, int& ct, int& m0, int& rb, int& cnt) {
+// for the three m from the same offsets and takes the smallest (ties: the taller tile).  With `split_tail` the units
+// of the last, partial round run as TWO half-width workgroups each (half = 0 / 1: 64 of the 128 outputs, the four
+// waves as 2 column x 2 row groups) when twice their number still fits the slots -- the round then costs half.
+__device__ __forceinline__ bool find_unit_rb(const int32_t* offsets, int E, int ncol, int slots, bool split_tail, int bid, int& e, int& ct, int& m0, int& rb, int& cnt, int& half) {
   const int lane = threadIdx.x & 63;
   int U[4] = {0, 0, 0, 0}, nbtot = 0;
   for (int base = 0; base < E; base += 64) {
@@ -371,12 +373,26 @@ __device__ __forceinline__ bool find_unit_rb(const int32_t* offsets, int E, int 
   for (int m = 4; m >= 2; --m) {  // (m = 1 is left out: it would double the grid bound the host must launch)
     const int u = U[m - 1] * ncol;
     if (u == 0) return false;
-    const float est = (float)((u + slots - 1) / slots) * ((float)(nbtot * ncol) / (float)u + 0.35f);
+    const float blocks = (float)(nbtot * ncol) / (float)u;
+    const int full = u / slots, r = u - full * slots;
+    // the last, partial round: its units run as two half-width workgroups each when they fit (split_tail)
+    const float tail = r == 0 ? 0.f : ((split_tail && 2 * r <= slots) ? 0.6f * blocks + 0.35f : blocks + 0.35f);  // (0.6: both halves stage the whole A tile)
+    const float est = (float)full * (blocks + 0.35f) + tail;
     if (est < best) { best = est; mbest = m; }
   }
-  const int total = U[mbest - 1] * ncol;
-  if (bid >= total) return false;
-  int u = xcd_remap(bid, total);
+  const int units = U[mbest - 1] * ncol;
+  const int nfull = (units / slots) * slots, r = units - nfull;
+  const bool split = split_tail && r > 0 && 2 * r <= slots;
+  if (bid >= nfull + (split ? 2 * r : r)) return false;
+  int u;
+  half = -1;
+  if (bid < nfull) {
+    u = xcd_remap(bid, nfull);
+  } else {
+    const int v = xcd_remap(bid - nfull, split ? 2 * r : r);  // (nfull is a multiple of 8: the XCD of a workgroup is unchanged)
+    u = nfull + (split ? v >> 1 : v);
+    if (split) half = v & 1;
+  }
   for (int base = 0; base < E; base += 64) {
     const int j = base + lane;
     const int c = j < E ? offsets[j + 1] - offsets[j] : 0;
@@ -401,11 +417,11 @@ __device__ __forceinline__ bool find_unit_rb(const int32_t* offsets, int E, int 
   return false;
 }
 
-template <int RB>
-__device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct, int m0, int cnt, float* smem, int* prow) {
+template <int RB, bool HALF>
+__device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct, int m0, int cnt, int half, float* smem, int* prow) {
   constexpr int BK = 32, LS = BK + 4, BN = 128, ROWS = 32 * RB;
   constexpr int STAGE = (128 + BN) * LS;  // floats per LDS stage: A rows [0, 128), W rows [128, 256)
-  const int n0 = ct * BN;
+  const int n0 = ct * BN + (HALF ? 64 * half : 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   // per row of the tile, computed once by one thread: byte offset of its source row in A and of its output row in
   // Y (rows past the expert's pairs: an offset past the buffers -- loads return zeros, stores are dropped)
@@ -430,12 +446,13 @@ __device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, (int)((int64_t)g.N * g.Kd * 4), 0x00020000);
-  constexpr int NS = RB + 4;  // staged float4 per thread and step: slots [0, RB) = A, [RB, NS) = W
+  constexpr int NWS = HALF ? 2 : 4;  // W rows staged per thread: 128 outputs, 64 in a half-width unit
+  constexpr int NS = RB + NWS;  // staged float4 per thread and step: slots [0, RB) = A, [RB, NS) = W
   int goff[NS];
 #pragma unroll
   for (int j = 0; j < RB; ++j) goff[j] = arow_off[sr + 32 * j] + sc * 4;  // (PAST + sc * 4 stays past the buffer)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) goff[RB + j] = (int)(((int64_t)(n0 + sr + 32 * j) * g.Kd + sc) * 4);  // rows >= N: past the buffer
+  for (int j = 0; j < NWS; ++j) goff[RB + j] = (int)(((int64_t)(n0 + sr + 32 * j) * g.Kd + sc) * 4);  // rows >= N: past the buffer
   float4 stg[NS];
   // (the k offset goes into the vector offset: that is the part the hardware range check covers)
   auto gload = [&](int i, int k0) {  // (two calls, not a select between the descriptors: that would make them "divergent")
@@ -452,9 +469,15 @@ __device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct
   const int rot = (e * g.ncol + ct) % nk;
   auto kof = [&](int kt) { int k = min(kt, nk - 1) + rot; k -= (k >= nk) ? nk : 0; return k * BK; };
 
-  f32x16 acc[RB];
+  // full unit: wave w owns outputs 32 w .. and all RB row blocks.  Half-width unit: wave (cw, rw) owns outputs
+  // 32 cw .. and the row blocks rw, rw + 2.
+  constexpr int NA = HALF ? (RB + 1) / 2 : RB;
+  const int cw = HALF ? (wave & 1) : wave, rw = HALF ? (wave >> 1) : 0;
+  constexpr int RSTEP = HALF ? 2 : 1;
+  const bool last_ok = !HALF || (RB % 2 == 0) || rw == 0;  // odd RB: the second row group has one block fewer
+  f32x16 acc[NA];
 #pragma unroll
-  for (int j = 0; j < RB; ++j) acc[j] = zero16();
+  for (int j = 0; j < NA; ++j) acc[j] = zero16();
   // pipeline: during step t (MFMAs on LDS stage t & 1) every thread moves its NS pieces of tile t + 1 from
   // registers to the other stage and refills each register with its piece of tile t + 2 -- one ds_write and
   // one buffer load between groups of MFMAs, ONE barrier per step, every vmcnt wait a counted one.
@@ -466,23 +489,23 @@ __device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct
   for (int i = 0; i < NS; ++i) gload(i, kof(1));
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered in the state its back edge leaves
   __syncthreads();
-  const int a_rd = ln * LS + 16 * hf, w_rd = (128 + 32 * wave + ln) * LS + 16 * hf;
+  const int a_rd = (32 * rw + ln) * LS + 16 * hf, w_rd = (128 + 32 * cw + ln) * LS + 16 * hf;
   for (int kt = 0; kt < nk; ++kt) {
     const float* cur = smem + (kt & 1) * STAGE;
     float* nxt = smem + ((kt + 1) & 1) * STAGE;
     const int k2 = kof(kt + 2);
-    float4 a[RB], b = ld4(cur + w_rd);
+    float4 a[NA], b = ld4(cur + w_rd);
 #pragma unroll
-    for (int j = 0; j < RB; ++j) a[j] = ld4(cur + a_rd + 32 * j * LS);
+    for (int j = 0; j < NA; ++j) a[j] = ld4(cur + a_rd + 32 * RSTEP * j * LS);
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      float4 an[RB], bn = b;
+      float4 an[NA], bn = b;
 #pragma unroll
-      for (int j = 0; j < RB; ++j) an[j] = a[j];
+      for (int j = 0; j < NA; ++j) an[j] = a[j];
       if (s4 + 1 < 4) {
         bn = ld4(cur + w_rd + 4 * (s4 + 1));
 #pragma unroll
-        for (int j = 0; j < RB; ++j) an[j] = ld4(cur + a_rd + 32 * j * LS + 4 * (s4 + 1));
+        for (int j = 0; j < NA; ++j) an[j] = ld4(cur + a_rd + 32 * RSTEP * j * LS + 4 * (s4 + 1));
       }
       // this group's share of the tile movement
 #pragma unroll
@@ -494,26 +517,31 @@ __device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
 #pragma unroll
-        for (int j = 0; j < RB; ++j) acc[j] = mfma32(f4(a[j], x), f4(b, x), acc[j]);
+        for (int j = 0; j < NA - 1; ++j) acc[j] = mfma32(f4(a[j], x), f4(b, x), acc[j]);
+      }
+      if (last_ok) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[NA - 1] = mfma32(f4(a[NA - 1], x), f4(b, x), acc[NA - 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
       b = bn;
 #pragma unroll
-      for (int j = 0; j < RB; ++j) a[j] = an[j];
+      for (int j = 0; j < NA; ++j) a[j] = an[j];
     }
     __syncthreads();
   }
   // epilogue: one add and one range-checked buffer store per element (rows past the pairs and columns past N
   // carry offsets past the buffer and are dropped by the hardware: no compares, branches or 64-bit products)
-  const int n = n0 + 32 * wave + ln;
+  const int n = n0 + 32 * cw + ln;
   const float bv = (g.bias && n < g.N) ? g.bias[(int64_t)e * g.N + n] : 0.f;
   const unsigned coff = n < g.N ? (unsigned)n * 4u : COL_PAST;
   const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.Y, 0, (int)g.y_bytes, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < RB; ++j) {
+  for (int j = 0; j < NA; ++j) {
+    if (j == NA - 1 && !last_ok) break;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const unsigned yo = (unsigned)yrow_off[32 * j + acc_row(r, hf)];
+      const unsigned yo = (unsigned)yrow_off[32 * (rw + RSTEP * j) + acc_row(r, hf)];
       if (g.y_div > 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[j][r] + bv, y_rsrc, (int)(yo + coff), 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] + bv), y_rsrc, (int)(yo + coff), 0, 0);
     }
@@ -523,26 +551,33 @@ __device__ __forceinline__ void nt_panel_body(const GemmParams& g, int e, int ct
 __global__ __launch_bounds__(256, 2) void grouped_nt_wide_kernel(GemmParams g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (128 + 128) * 36];
   __shared__ int prow[256];
-  int e, ct, m0, rb, cnt;
-  if (!find_unit_rb(g.offsets, g.E, g.ncol, g.slots, blockIdx.x, e, ct, m0, rb, cnt)) return;
+  int e, ct, m0, rb, cnt, half;
+  if (!find_unit_rb(g.offsets, g.E, g.ncol, g.slots, true, blockIdx.x, e, ct, m0, rb, cnt, half)) return;
   // (wave-uniform by construction; said again here, or the weight panel's buffer descriptor counts as divergent
   // and every load through it is wrapped in a waterfall loop)
   e = __builtin_amdgcn_readfirstlane(e); ct = __builtin_amdgcn_readfirstlane(ct); m0 = __builtin_amdgcn_readfirstlane(m0);
-  rb = __builtin_amdgcn_readfirstlane(rb); cnt = __builtin_amdgcn_readfirstlane(cnt);
-  if (rb == 4) nt_panel_body<4>(g, e, ct, m0, cnt, smem, prow);
-  else if (rb == 3) nt_panel_body<3>(g, e, ct, m0, cnt, smem, prow);
-  else if (rb == 2) nt_panel_body<2>(g, e, ct, m0, cnt, smem, prow);
-  else nt_panel_body<1>(g, e, ct, m0, cnt, smem, prow);
+  rb = __builtin_amdgcn_readfirstlane(rb); cnt = __builtin_amdgcn_readfirstlane(cnt); half = __builtin_amdgcn_readfirstlane(half);
+  if (half < 0) {
+    if (rb == 4) nt_panel_body<4, false>(g, e, ct, m0, cnt, 0, smem, prow);
+    else if (rb == 3) nt_panel_body<3, false>(g, e, ct, m0, cnt, 0, smem, prow);
+    else if (rb == 2) nt_panel_body<2, false>(g, e, ct, m0, cnt, 0, smem, prow);
+    else nt_panel_body<1, false>(g, e, ct, m0, cnt, 0, smem, prow);
+  } else {
+    if (rb == 4) nt_panel_body<4, true>(g, e, ct, m0, cnt, half, smem, prow);
+    else if (rb == 3) nt_panel_body<3, true>(g, e, ct, m0, cnt, half, smem, prow);
+    else if (rb == 2) nt_panel_body<2, true>(g, e, ct, m0, cnt, half, smem, prow);
+    else nt_panel_body<1, true>(g, e, ct, m0, cnt, half, smem, prow);
+  }
 }
 
 // The input-gradient product Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk] on the same pipeline: tiles of
 // RB 32-row blocks x 128 outputs (kk) x 32 deep (n).  W is consumed as stored, (n, kk) rows: the B operand of a
 // step is a column of the staged (32 n x 128 kk) slab -- ds_read_b32, consecutive lanes on consecutive kk.
-template <int RB>
-__device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct, int m0, int cnt, float* smem, int* prow) {
+template <int RB, bool HALF>
+__device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct, int m0, int cnt, int half, float* smem, int* prow) {
   constexpr int BK = 32, LS = BK + 4, BN = 128, WS = BN + 4, ROWS = 32 * RB;
   constexpr int A_FLOATS = 128 * LS, STAGE = A_FLOATS + BK * WS;  // per stage: A rows [0, 128), then the W slab
-  const int c0 = ct * BN;
+  const int c0 = ct * BN + (HALF ? 64 * half : 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   constexpr unsigned PAST = 0x80000000u, COL_PAST = 0x7FFF0000u;  // as in nt_panel_body
   int* arow_off = prow;
@@ -564,18 +599,20 @@ __device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct
   __syncthreads();
   // staging: A 8 threads per row (rows sr + 32 j, j < RB); W 32 threads per n row (rows wr + 8 j, j < 4)
   const int sr = tid >> 3, sc = (tid & 7) * 4;
-  const int wr = tid >> 5, wc = (tid & 31) * 4;
+  constexpr int WTPR = HALF ? 16 : 32;      // threads per W slab row (16 B each): 128 outputs, 64 in a half-width unit
+  constexpr int NWS = HALF ? 2 : 4;         // passes over the 32 n rows of the slab
+  const int wr = tid / WTPR, wc = (tid % WTPR) * 4;
   const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, (int)g.a_bytes, 0x00020000);
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
   const __amdgpu_buffer_rsrc_t w_rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, (int)((int64_t)g.N * g.Kd * 4), 0x00020000);
-  constexpr int NS = RB + 4;
+  constexpr int NS = RB + NWS;
   int goff[NS];
 #pragma unroll
   for (int j = 0; j < RB; ++j) goff[j] = arow_off[sr + 32 * j] + sc * 4;
   // columns >= Kd: the whole thread reads past the buffer (zeros)
 #pragma unroll
-  for (int j = 0; j < 4; ++j) goff[RB + j] = c0 + wc < g.Kd ? (int)(((int64_t)(wr + 8 * j) * g.Kd + c0 + wc) * 4) : (int)PAST;
+  for (int j = 0; j < NWS; ++j) goff[RB + j] = c0 + wc < g.Kd ? (int)(((int64_t)(wr + (256 / WTPR) * j) * g.Kd + c0 + wc) * 4) : (int)PAST;
   const int wstep = g.Kd * 4;  // bytes per n row of W
   float4 stg[NS];
   auto gload = [&](int i, int k0) {
@@ -584,15 +621,20 @@ __device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct
   };
   auto lstore = [&](int i, float* stage) {
     if (i < RB) st4(&stage[(sr + 32 * i) * LS + sc], stg[i]);
-    else st4(&stage[A_FLOATS + (wr + 8 * (i - RB)) * WS + wc], stg[i]);
+    else st4(&stage[A_FLOATS + (wr + (256 / WTPR) * (i - RB)) * WS + wc], stg[i]);
   };
   const int nk = g.N / BK;
   const int rot = (e * g.ncol + ct) % nk;
   auto kof = [&](int kt) { int k = min(kt, nk - 1) + rot; k -= (k >= nk) ? nk : 0; return k * BK; };
 
-  f32x16 acc[RB];
+  // half-width unit: wave (cw, rw) owns outputs 32 cw .. and the row blocks rw, rw + 2 (as in nt_panel_body)
+  constexpr int NA = HALF ? (RB + 1) / 2 : RB;
+  const int cw = HALF ? (wave & 1) : wave, rw = HALF ? (wave >> 1) : 0;
+  constexpr int RSTEP = HALF ? 2 : 1;
+  const bool last_ok = !HALF || (RB % 2 == 0) || rw == 0;
+  f32x16 acc[NA];
 #pragma unroll
-  for (int j = 0; j < RB; ++j) acc[j] = zero16();
+  for (int j = 0; j < NA; ++j) acc[j] = zero16();
 #pragma unroll
   for (int i = 0; i < NS; ++i) gload(i, kof(0));
 #pragma unroll
@@ -601,28 +643,28 @@ __device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct
   for (int i = 0; i < NS; ++i) gload(i, kof(1));
   __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered in the state its back edge leaves
   __syncthreads();
-  const int a_rd = ln * LS + 16 * hf, w_rd = A_FLOATS + (16 * hf) * WS + 32 * wave + ln;
+  const int a_rd = (32 * rw + ln) * LS + 16 * hf, w_rd = A_FLOATS + (16 * hf) * WS + 32 * cw + ln;
   for (int kt = 0; kt < nk; ++kt) {
     const float* cur = smem + (kt & 1) * STAGE;
     float* nxt = smem + ((kt + 1) & 1) * STAGE;
     const int k2 = kof(kt + 2);
-    float4 a[RB];
+    float4 a[NA];
     float b[4];
 #pragma unroll
-    for (int j = 0; j < RB; ++j) a[j] = ld4(cur + a_rd + 32 * j * LS);
+    for (int j = 0; j < NA; ++j) a[j] = ld4(cur + a_rd + 32 * RSTEP * j * LS);
 #pragma unroll
     for (int x = 0; x < 4; ++x) b[x] = cur[w_rd + x * WS];
 #pragma unroll
     for (int s4 = 0; s4 < 4; ++s4) {
-      float4 an[RB];
+      float4 an[NA];
       float bn[4];
 #pragma unroll
-      for (int j = 0; j < RB; ++j) an[j] = a[j];
+      for (int j = 0; j < NA; ++j) an[j] = a[j];
 #pragma unroll
       for (int x = 0; x < 4; ++x) bn[x] = b[x];
       if (s4 + 1 < 4) {
 #pragma unroll
-        for (int j = 0; j < RB; ++j) an[j] = ld4(cur + a_rd + 32 * j * LS + 4 * (s4 + 1));
+        for (int j = 0; j < NA; ++j) an[j] = ld4(cur + a_rd + 32 * RSTEP * j * LS + 4 * (s4 + 1));
 #pragma unroll
         for (int x = 0; x < 4; ++x) bn[x] = cur[w_rd + (4 * (s4 + 1) + x) * WS];
       }
@@ -635,24 +677,29 @@ __device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
 #pragma unroll
-        for (int j = 0; j < RB; ++j) acc[j] = mfma32(f4(a[j], x), b[x], acc[j]);
+        for (int j = 0; j < NA - 1; ++j) acc[j] = mfma32(f4(a[j], x), b[x], acc[j]);
+      }
+      if (last_ok) {
+#pragma unroll
+        for (int x = 0; x < 4; ++x) acc[NA - 1] = mfma32(f4(a[NA - 1], x), b[x], acc[NA - 1]);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int j = 0; j < RB; ++j) a[j] = an[j];
+      for (int j = 0; j < NA; ++j) a[j] = an[j];
 #pragma unroll
       for (int x = 0; x < 4; ++x) b[x] = bn[x];
     }
     __syncthreads();
   }
-  const int c = c0 + 32 * wave + ln;
+  const int c = c0 + 32 * cw + ln;
   const unsigned coff = c < g.Kd ? (unsigned)c * 4u : COL_PAST;
   const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)g.Y, 0, (int)g.y_bytes, 0x00020000);
 #pragma unroll
-  for (int j = 0; j < RB; ++j) {
+  for (int j = 0; j < NA; ++j) {
+    if (j == NA - 1 && !last_ok) break;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = 32 * j + acc_row(r, hf);
+      const int row = 32 * (rw + RSTEP * j) + acc_row(r, hf);
       if (g.y_div > 0) __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[j][r] * srow[row], y_rsrc, (int)((unsigned)yrow_off[row] + coff), 0, 0);
       else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, acc[j][r] * srow[row]), y_rsrc, (int)((unsigned)yrow_off[row] + coff), 0, 0);
     }
@@ -662,14 +709,21 @@ __device__ __forceinline__ void nn_panel_body(const GemmParams& g, int e, int ct
 __global__ __launch_bounds__(256, 2) void grouped_nn_wide_kernel(GemmParams g) {
   __shared__ __attribute__((aligned(16))) float smem[2 * (128 * 36 + 32 * 132)];
   __shared__ int prow[384];
-  int e, ct, m0, rb, cnt;
-  if (!find_unit_rb(g.offsets, g.E, g.ncol, g.slots, blockIdx.x, e, ct, m0, rb, cnt)) return;
+  int e, ct, m0, rb, cnt, half;
+  if (!find_unit_rb(g.offsets, g.E, g.ncol, g.slots, true, blockIdx.x, e, ct, m0, rb, cnt, half)) return;
   e = __builtin_amdgcn_readfirstlane(e); ct = __builtin_amdgcn_readfirstlane(ct); m0 = __builtin_amdgcn_readfirstlane(m0);
-  rb = __builtin_amdgcn_readfirstlane(rb); cnt = __builtin_amdgcn_readfirstlane(cnt);
-  if (rb == 4) nn_panel_body<4>(g, e, ct, m0, cnt, smem, prow);
-  else if (rb == 3) nn_panel_body<3>(g, e, ct, m0, cnt, smem, prow);
-  else if (rb == 2) nn_panel_body<2>(g, e, ct, m0, cnt, smem, prow);
-  else nn_panel_body<1>(g, e, ct, m0, cnt, smem, prow);
+  rb = __builtin_amdgcn_readfirstlane(rb); cnt = __builtin_amdgcn_readfirstlane(cnt); half = __builtin_amdgcn_readfirstlane(half);
+  if (half < 0) {
+    if (rb == 4) nn_panel_body<4, false>(g, e, ct, m0, cnt, 0, smem, prow);
+    else if (rb == 3) nn_panel_body<3, false>(g, e, ct, m0, cnt, 0, smem, prow);
+    else if (rb == 2) nn_panel_body<2, false>(g, e, ct, m0, cnt, 0, smem, prow);
+    else nn_panel_body<1, false>(g, e, ct, m0, cnt, 0, smem, prow);
+  } else {
+    if (rb == 4) nn_panel_body<4, true>(g, e, ct, m0, cnt, half, smem, prow);
+    else if (rb == 3) nn_panel_body<3, true>(g, e, ct, m0, cnt, half, smem, prow);
+    else if (rb == 2) nn_panel_body<2, true>(g, e, ct, m0, cnt, half, smem, prow);
+    else nn_panel_body<1, true>(g, e, ct, m0, cnt, half, smem, prow);
+  }
 }
 
 // Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk]              tile: 64 pairs x 64*NB outputs
@@ -1199,7 +1253,7 @@ static int grouped_nt_impl(const char* who, const float* A, int64_t lda, int a_d
   AMK_CHECK_SUPPORTED(y_div == 0 || wide, "%s: the accumulating form needs N >= 128, Kd %% 32 == 0 and buffers below 2 GB", who);
   if (wide && (y_div > 0 || !getenv("AMK_MOE_NARROW")))
     { g.ncol = (N + 127) / 128; g.slots = wg_slots();  // grid: the bound for two-block tiles; the surplus workgroups leave at once
-      hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3((unsigned)((P + 63) / 64 + E) * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+      hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3((unsigned)((P + 63) / 64 + E) * g.ncol + (unsigned)g.slots / 2), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else
     { g.ncol = (N + 63) / 64; hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH(who);
@@ -1235,7 +1289,7 @@ static int grouped_nn_impl(const char* who, const float* A, int64_t lda, int a_d
   AMK_CHECK_SUPPORTED(y_div == 0 || wide, "%s: the accumulating form needs Kd >= 128, N %% 32 == 0 and buffers below 2 GB", who);
   if (wide && (y_div > 0 || !getenv("AMK_MOE_NARROW"))) {
     g.ncol = (Kd + 127) / 128; g.slots = wg_slots();
-    hipLaunchKernelGGL(grouped_nn_wide_kernel, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    hipLaunchKernelGGL(grouped_nn_wide_kernel, dim3(mt * g.ncol + (unsigned)g.slots / 2), dim3(256), 0, static_cast<hipStream_t>(stream), g);
   } else if (Kd > 64) { g.ncol = (Kd + 127) / 128; hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else { g.ncol = 1; hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH(who);
