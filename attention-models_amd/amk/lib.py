@@ -36,6 +36,7 @@ SIGNATURES = {
     "amk_vq_num_partials": (_L, [_L]),
     "amk_vq_lookup_fwd": (_I, [_P, _P, _L, _I, _I, _I] + [_P] * 9 + [_P]),
     "amk_vq_lookup_bwd": (_I, [_P] * 7 + [_F, _L, _I, _I, _P, _P, _P]),
+    "amk_vq_lookup_bwd_rows": (_I, [_P] * 7 + [_F, _L, _I, _I, _P, _P, _P]),
     "amk_vq_padded_codes": (_I, [_I, _I]),
     "amk_vq_gather": (_I, [_P, _P, _L, _I, _I, _P, _P, _P]),
     "amk_agent_num_chunks": (_I, [_I]),

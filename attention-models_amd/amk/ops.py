@@ -367,8 +367,24 @@ class _VQLookup(torch.autograd.Function):
         g_out = g_out.contiguous().view(N, C)
         g_loss = g_loss.contiguous().to(torch.float32)
         dz = torch.empty_like(zf)
-        dcb = torch.empty_like(cb)
         L = _lib.load()
+        if DETERMINISTIC_ATTENTION_BACKWARD or torch.are_deterministic_algorithms_enabled():
+            # reproducible codebook gradient: per-row contributions, added in a fixed order (torch's deterministic
+            # index_add_ sorts by index) instead of the kernel's f32 atomics
+            ge = torch.empty_like(zf)
+            rc = L.amk_vq_lookup_bwd_rows(
+                _ptr(zf), _ptr(cb), _ptr(zn), _ptr(zq), _ptr(idx), _ptr(g_out), _ptr(g_loss),
+                float(ctx.beta), N, K, C, _ptr(dz), _ptr(ge), _stream(),
+            )
+            _lib.check(rc, "amk_vq_lookup_bwd_rows")
+            was = torch.are_deterministic_algorithms_enabled()
+            torch.use_deterministic_algorithms(True)
+            try:
+                dcb = torch.zeros_like(cb).index_add_(0, idx.clamp(0, K - 1), ge)
+            finally:
+                torch.use_deterministic_algorithms(was)
+            return dz.view(ctx.z_shape), dcb, None
+        dcb = torch.empty_like(cb)
         rc = L.amk_vq_lookup_bwd(
             _ptr(zf), _ptr(cb), _ptr(zn), _ptr(zq), _ptr(idx), _ptr(g_out), _ptr(g_loss),
             float(ctx.beta), N, K, C, _ptr(dz), _ptr(dcb), _stream(),

@@ -298,7 +298,7 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ z
                                                      const float* __restrict__ zn, const float* __restrict__ zq,
                                                      const int64_t* __restrict__ idx, const float* __restrict__ g_out,
                                                      const float* __restrict__ g_loss, float beta, int64_t N, int K,
-                                                     float* __restrict__ dz, float* __restrict__ dE) {
+                                                     float* __restrict__ dz, float* __restrict__ dE, float* __restrict__ ge_rows) {
   // one lane per element, C lanes per row: the codebook atomics of a wave then form
   // 64/C whole 4*C-byte row segments per instruction.
   constexpr int RPB = 256 / C;
@@ -331,7 +331,8 @@ __global__ __launch_bounds__(256) void vq_bwd_kernel(const float* __restrict__ z
   const float ge = (ne > EPS) ? (dzq - zqv * pq) / ne : dzq / EPS;
   if (valid) {
     dz[off] = gz;
-    atomicAdd(dE + code * C + c, ge);
+    if (ge_rows) ge_rows[off] = ge;  // the caller adds the rows into the codebook gradient in a fixed order
+    else atomicAdd(dE + code * C + c, ge);
   }
 }
 
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void vq_bwd_wide_kernel(const float* __restric
                                                           const float* __restrict__ zn, const float* __restrict__ zq,
                                                           const int64_t* __restrict__ idx, const float* __restrict__ g_out,
                                                           const float* __restrict__ g_loss, float beta, int64_t N, int K,
-                                                          float* __restrict__ dz, float* __restrict__ dE) {
+                                                          float* __restrict__ dz, float* __restrict__ dE, float* __restrict__ ge_rows) {
   constexpr int LPR = C / 4;
   const int64_t row = (int64_t)blockIdx.x * (256 / LPR) + threadIdx.x / LPR;
   const int c = (threadIdx.x % LPR) * 4;
@@ -382,7 +383,8 @@ __global__ __launch_bounds__(256) void vq_bwd_wide_kernel(const float* __restric
     for (int e = 0; e < 4; ++e) {
       gz[e] = (nz > EPS) ? (dzn[e] - znA[e] * pz) / nz : dzn[e] / EPS;
       const float ge = (ne > EPS) ? (dzq[e] - zqA[e] * pq) / ne : dzq[e] / EPS;
-      atomicAdd(dE + code * C + c + e, ge);
+      if (ge_rows) ge_rows[off + e] = ge;
+      else atomicAdd(dE + code * C + c + e, ge);
     }
     st4(dz + off, make_float4(gz[0], gz[1], gz[2], gz[3]));
   }
@@ -464,31 +466,45 @@ extern "C" int amk_vq_lookup_fwd(const float* z, const float* codebook, int64_t 
   return AMK_OK;
 }
 
-extern "C" int amk_vq_lookup_bwd(const float* z, const float* codebook, const float* zn, const float* zq,
-                                 const int64_t* idx, const float* g_out, const float* g_loss, float beta,
-                                 int64_t N, int K, int C, float* dz, float* dcodebook, void* stream) {
-  AMK_CHECK_ARG(z && codebook && zn && zq && idx && g_out && g_loss && dz && dcodebook, "amk_vq_lookup_bwd: null pointer");
-  AMK_CHECK_ARG(N > 0 && K > 0, "amk_vq_lookup_bwd: non-positive size");
-  AMK_CHECK_SUPPORTED(C == 32 || C == 64 || C == 128 || C == 256, "amk_vq_lookup_bwd: codebook_dim %d not supported (32, 64, 128, 256)", C);
+static int vq_bwd_impl(const char* who, const float* z, const float* codebook, const float* zn, const float* zq,
+                       const int64_t* idx, const float* g_out, const float* g_loss, float beta,
+                       int64_t N, int K, int C, float* dz, float* dcodebook, float* ge_rows, void* stream) {
+  AMK_CHECK_ARG(z && codebook && zn && zq && idx && g_out && g_loss && dz && (dcodebook || ge_rows), "%s: null pointer", who);
+  AMK_CHECK_ARG(N > 0 && K > 0, "%s: non-positive size", who);
+  AMK_CHECK_SUPPORTED(C == 32 || C == 64 || C == 128 || C == 256, "%s: codebook_dim %d not supported (32, 64, 128, 256)", who, C);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (hipMemsetAsync(dcodebook, 0, (size_t)K * C * sizeof(float), st) != hipSuccess) {
-    amk_set_error("amk_vq_lookup_bwd: hipMemsetAsync failed");
+  if (!ge_rows && hipMemsetAsync(dcodebook, 0, (size_t)K * C * sizeof(float), st) != hipSuccess) {
+    amk_set_error("%s: hipMemsetAsync failed", who);
     return AMK_ELAUNCH;
   }
   const int rpb = C <= 64 ? 256 / C : 256 / (C / 4);
   const int64_t nb = (N + rpb - 1) / rpb;
-  AMK_CHECK_SUPPORTED(nb < (1ll << 31), "amk_vq_lookup_bwd: grid too large");
-  AMK_CHECK_ARG(C <= 64 || (a16(z) && a16(codebook) && a16(zn) && a16(zq) && a16(g_out) && a16(dz)), "amk_vq_lookup_bwd: pointers must be 16-byte aligned");
+  AMK_CHECK_SUPPORTED(nb < (1ll << 31), "%s: grid too large", who);
+  AMK_CHECK_ARG(C <= 64 || (a16(z) && a16(codebook) && a16(zn) && a16(zq) && a16(g_out) && a16(dz)), "%s: pointers must be 16-byte aligned", who);
   if (C == 32)
-    hipLaunchKernelGGL(vq_bwd_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook);
+    hipLaunchKernelGGL(vq_bwd_kernel<32>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook, ge_rows);
   else if (C == 64)
-    hipLaunchKernelGGL(vq_bwd_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook);
+    hipLaunchKernelGGL(vq_bwd_kernel<64>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook, ge_rows);
   else if (C == 128)
-    hipLaunchKernelGGL(vq_bwd_wide_kernel<128>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook);
+    hipLaunchKernelGGL(vq_bwd_wide_kernel<128>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook, ge_rows);
   else
-    hipLaunchKernelGGL(vq_bwd_wide_kernel<256>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook);
-  AMK_CHECK_LAUNCH("amk_vq_lookup_bwd");
+    hipLaunchKernelGGL(vq_bwd_wide_kernel<256>, dim3((unsigned)nb), dim3(256), 0, st, z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, dz, dcodebook, ge_rows);
+  AMK_CHECK_LAUNCH(who);
   return AMK_OK;
+}
+
+extern "C" int amk_vq_lookup_bwd(const float* z, const float* codebook, const float* zn, const float* zq,
+                                 const int64_t* idx, const float* g_out, const float* g_loss, float beta,
+                                 int64_t N, int K, int C, float* dz, float* dcodebook, void* stream) {
+  AMK_CHECK_ARG(dcodebook, "amk_vq_lookup_bwd: null pointer");
+  return vq_bwd_impl("amk_vq_lookup_bwd", z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, C, dz, dcodebook, nullptr, stream);
+}
+
+extern "C" int amk_vq_lookup_bwd_rows(const float* z, const float* codebook, const float* zn, const float* zq,
+                                      const int64_t* idx, const float* g_out, const float* g_loss, float beta,
+                                      int64_t N, int K, int C, float* dz, float* ge_rows, void* stream) {
+  AMK_CHECK_ARG(ge_rows, "amk_vq_lookup_bwd_rows: null pointer");
+  return vq_bwd_impl("amk_vq_lookup_bwd_rows", z, codebook, zn, zq, idx, g_out, g_loss, beta, N, K, C, dz, nullptr, ge_rows, stream);
 }
 
 extern "C" int amk_vq_gather(const int64_t* idx, const float* codebook, int64_t N, int K, int C, float* out,

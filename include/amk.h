@@ -206,6 +206,14 @@ int amk_vq_lookup_bwd(const float* z, const float* codebook, const float* zn, co
                       const int64_t* idx, const float* g_out, const float* g_loss, float beta,
                       int64_t N, int K, int C, float* dz, float* dcodebook, void* stream);
 
+/* The same backward without atomics: instead of scatter-adding into dcodebook, every row's contribution
+ * J_norm(E[idx[n]])^T dzq[n] is written to ge_rows (N,C); the caller adds the rows into dcodebook[idx[n]] in an
+ * order of its choosing (the Python binding uses a deterministic index_add_ when reproducible gradients are asked
+ * for: AMK_DETERMINISTIC=1 / torch.use_deterministic_algorithms). */
+int amk_vq_lookup_bwd_rows(const float* z, const float* codebook, const float* zn, const float* zq,
+                           const int64_t* idx, const float* g_out, const float* g_loss, float beta,
+                           int64_t N, int K, int C, float* dz, float* ge_rows, void* stream);
+
 /* Codebook.indices_to_embeddings (models/vitvqgan.py:173-176): out[n] = l2norm(E[idx[n]]).
  * The indices are the caller's: one outside [0, K) is never dereferenced (it reads row 0 or K-1) and
  * is counted in *bad_count (device int32, zeroed by the caller; NULL = do not count) -- the reference

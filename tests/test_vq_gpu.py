@@ -209,3 +209,31 @@ def test_vqgan_codebook_golden(device):
     assert_close(gE, fx["gE"], TOL, "grad codebook")
     emb = cb.indices_to_embeddings(idx.view(z.shape[0], -1))
     assert_close(emb, fx["emb"], 0.0, "indices_to_embeddings")
+
+
+@pytest.mark.parametrize("N,K,C", [(4096, 64, 32), (1000, 2048, 32), (513, 100, 256)])
+def test_reproducible_codebook_gradient(device, N, K, C):
+    """Under torch.use_deterministic_algorithms the codebook gradient -- a scatter-add of N rows into K codes, f32
+    atomics by default -- is built from per-row contributions added in a fixed order: equal to the oracle within
+    tolerance and bit-identical from call to call (few codes, many rows per code: the case atomics reorder)."""
+    from amk import ops
+
+    z = seeded((N, C), 1100 + N)
+    E = seeded((K, C), 2100 + K)
+    cot = seeded((N, C), 3100 + N)
+    zc, Ec = z.clone().requires_grad_(True), E.clone().requires_grad_(True)
+    zq_r, _, loss_r = ref_cpu.codebook_forward(zc, Ec, 0.25)
+    _, gE_r = torch.autograd.grad((zq_r * cot).sum() + 2.0 * loss_r, [zc, Ec])
+
+    def grads():
+        zd, Ed = z.to(device).requires_grad_(True), E.to(device).requires_grad_(True)
+        zq, _, loss = ops.vq_lookup(zd, Ed, 0.25)
+        return torch.autograd.grad((zq * cot.to(device)).sum() + 2.0 * loss, [zd, Ed])
+
+    torch.use_deterministic_algorithms(True)
+    try:
+        g1, g2 = grads(), grads()
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+    assert_close(g1[1], gE_r, TOL, "grad codebook (ordered)")
