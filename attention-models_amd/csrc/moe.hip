@@ -18,10 +18,18 @@
 //   combine        : out[g]  = sum_outer ( sum_{slots, ascending expert id} s[p] * Y[p] )
 //   gate_grad      : dlogit[u, ids[p]] = sigmoid'(.) * <dOut[p/g_div], Y[p]>
 //
-// A "pair" p = unit*k + slot.  Tiles are 64 pairs x 64 (or 128) outputs x 32 deep, 4 waves, one (or
-// two) 32x32 accumulators per wave with the OUTPUT FEATURE ON THE LANE (coalesced 128-B row segments on
-// store, per-lane bias), operands through LDS with row stride 36 / 68 floats (conflict-free
-// ds_read_b128 row reads, ds_read_b32 column reads).
+// A "pair" p = unit*k + slot.  Two generations of GEMM kernels live here:
+//   * grouped_{nt,nn}_wide_kernel, grouped_wgrad_wide_kernel (round 2; outputs >= 128 wide, weight gradients from
+//     64 wide): ONE software pipeline -- 32-row blocks in tiles of 2..4 blocks (height chosen per launch by every
+//     wave from the offsets) x 128 outputs x 32 deep, two LDS stages and one barrier per step, the tile movement
+//     (register -> LDS of tile t+1, global -> register of tile t+2) between the MFMA groups of tile t, units decoded
+//     by a wave scan, XCD-aware unit order, the last partial round as half-width units, range-checked buffer
+//     loads / stores instead of compares.  DESIGN.md section 4 has the measurements behind each of these.
+//   * grouped_{nt,nn,wgrad}_kernel<NB> (round 1): 64 pairs x 64 NB outputs x 32 deep, two barriers per step; still
+//     used for outputs narrower than 128 (SwitchHead's 64-wide experts) and depths that are not multiples of 32.
+// All of them: 4 waves, 32x32 f32 accumulators with the OUTPUT FEATURE ON THE LANE (coalesced 128-B row segments
+// on store, per-lane bias), operands through LDS with row stride 36 floats (conflict-free ds_read_b128 row reads,
+// ds_read_b32 column reads).
 #include "amk_common.h"
 #include <stdlib.h>
 
