@@ -76,21 +76,13 @@ def main():
                 d["mfma_busy_frac"] = d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4 * 256 * cycles)
                 d["valu_per_mfma"] = (d["SQ_INSTS_VALU"] - d["SQ_INSTS_MFMA"]) / d["SQ_INSTS_MFMA"]
         out[k] = d
-    # The kept-scores backward reads its score tiles as 16 B per lane at a 128-B lane stride (one key row per lane):
-    # not the wide coalesced stream the x2 FETCH_SIZE correction is calibrated for (MI355X_MICROARCH.md, HBM: "other
-    # access widths are uncalibrated: calibrate on a known byte count in your own access pattern").  The known count
-    # is the stream itself -- every score byte is read exactly once, and the forward's WRITE_SIZE shows its size --
-    # and the remaining loads (q, dO, k, v rows, statistics) are the recompute variant's, measured there.
-    kept, rec, fkeep, ffwd = (out.get(k) for k in ("attn_bwd_fused_kernel(kept scores)", "attn_bwd_fused_kernel",
-                                                   "attn_fwd_keep_kernel", "attn_fwd_kernel"))
-    if kept and rec and fkeep and ffwd:
-        scores = (fkeep["WRITE_SIZE_KiB"] - ffwd["WRITE_SIZE_KiB"]) * 1024
-        kept["score_stream_bytes"] = scores
-        kept["hbm_bytes_formula"] = kept["hbm_bytes_per_launch"]
-        kept["hbm_bytes_per_launch"] = 2 * rec["FETCH_SIZE_KiB"] * 1024 + scores + kept["WRITE_SIZE_KiB"] * 1024
-        kept["hbm_bytes_note"] = ("calibrated: 2 x FETCH_SIZE of the recompute variant (the same q / dO / k / v loads) + the score "
-                                  "stream at its known size (forward WRITE_SIZE with minus without kept scores) + WRITE_SIZE; the "
-                                  "uncalibrated formula 2 x FETCH_SIZE + WRITE_SIZE is in hbm_bytes_formula")
+    # (Round 2 first priced the kept-scores backward's score stream at its known size -- the x2 FETCH_SIZE correction
+    # is calibrated for wide coalesced streams and the tiles are read 16 B per lane -- because the guide's formula gave
+    # 1.38x the algorithmic bytes.  With the key blocks of a slice walking q / dO in step the formula itself gives
+    # 1.13x, so the figure reported is the guide's formula for every kernel; the score stream's size is kept as a note.)
+    kept, fkeep, ffwd = (out.get(k) for k in ("attn_bwd_fused_kernel(kept scores)", "attn_fwd_keep_kernel", "attn_fwd_kernel"))
+    if kept and fkeep and ffwd:
+        kept["score_stream_bytes"] = (fkeep["WRITE_SIZE_KiB"] - ffwd["WRITE_SIZE_KiB"]) * 1024
     about = a.about or ("rocprofv3 --pmc passes over `python tools/kbench.py --batch %d --iters 5` on one MI355X; separate passes "
                         "(SQ+GRBM set, FETCH_SIZE, WRITE_SIZE, TCC_EA0_ATOMIC_sum) as MI355X_MICROARCH.md prescribes; folded by "
                         "tools/pmc_digest.py" % a.batch)
