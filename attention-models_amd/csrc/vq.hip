@@ -248,9 +248,24 @@ __global__ __launch_bounds__(FIN_ROWS * C / 4) void vq_finalize_kernel(
   const int c = (threadIdx.x % LPR) * 4;
   float err = 0.f;
   if (row < N) {
-    float best = pmin[row * nsplit];
-    int bg = pidx[row * nsplit];
-    for (int s = 1; s < nsplit; ++s) {  // slices hold ascending code ranges: strict '>' keeps the first maximum
+    // all slices' partials first (independent loads in flight together; a load -> compare -> load loop was a
+    // chain of nsplit memory latencies in a 7-us kernel), then the merge: slices hold ascending code ranges,
+    // strict '>' keeps the first maximum
+    constexpr int MAXS = 16;
+    float pd[MAXS];
+    int pi[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+      const bool on = s < nsplit;
+      pd[s] = on ? pmin[row * nsplit + s] : -INFINITY;
+      pi[s] = on ? pidx[row * nsplit + s] : 0;
+    }
+    float best = pd[0];
+    int bg = pi[0];
+#pragma unroll
+    for (int s = 1; s < MAXS; ++s)
+      if (pd[s] > best) { best = pd[s]; bg = pi[s]; }
+    for (int s = MAXS; s < nsplit; ++s) {  // (more than 16 slices: not chosen by vq_nsplit, kept correct)
       const float d = pmin[row * nsplit + s];
       if (d > best) { best = d; bg = pidx[row * nsplit + s]; }
     }
