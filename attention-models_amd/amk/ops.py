@@ -215,10 +215,19 @@ def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, sc
         call(stages)
 
 
+# Mixed precision (the reference's shipped config trains under accelerate's bf16 autocast, cfg/vitvqgan.yaml:73): the
+# kernels here are f32, so inside a torch.autocast region every autograd Function below takes its floating-point
+# inputs as f32 (custom_fwd(cast_inputs=float32): bf16 activations coming out of autocast Linear layers are upcast,
+# the op runs with autocast off) and hands f32 back; the library GEMMs around them run in bf16 as autocast decides.
+_amp_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_amp_bwd = torch.amp.custom_bwd(device_type="cuda")
+
+
 class _AttnCore(torch.autograd.Function):
     """o = softmax(fill(q*scale @ k^T)) @ v on (B,H,T,D) views."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, q, k, v, key_mask, causal_mask, scale):
         need = any(ctx.needs_input_grad[:3])
         q, k, v, o, stats, scores = _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=need)
@@ -227,6 +236,7 @@ class _AttnCore(torch.autograd.Function):
         return o
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, d_o):
         q, k, v, o, stats, key_mask, causal_mask, scores = ctx.saved_tensors
         B, H, I, D = q.shape
@@ -244,6 +254,7 @@ class _AttnFusedKV(torch.autograd.Function):
     The backward writes dk and dv straight into one (B,J,2*h*d) buffer."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, q2, kv2, key_mask, causal_mask, H, D, scale):
         B, I, _ = q2.shape
         J = kv2.shape[1]
@@ -260,6 +271,7 @@ class _AttnFusedKV(torch.autograd.Function):
         return o.permute(0, 2, 1, 3).reshape(B, I, H * D)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, d_o2):
         q, k, v, o, stats, key_mask, causal_mask, scores = ctx.saved_tensors
         B, H, I, D = q.shape
@@ -318,6 +330,7 @@ def vq_nsplit(N, K):
 
 class _VQLookup(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, z, codebook, beta):
         _require_device(z, codebook)
         C = z.shape[-1]
@@ -356,6 +369,7 @@ class _VQLookup(torch.autograd.Function):
         return out.view(z.shape), idx_v, loss
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, g_out, _g_idx, g_loss):
         zf, cb, zn, zq, idx = ctx.saved_tensors
         N, C = zf.shape
@@ -495,6 +509,7 @@ class _RoutedLinear(torch.autograd.Function):
     moe_out).  Returns (out (U/outer, N), ids (U,k) int64)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x2, logits2, W, bias, k, x_div, weighted, outer):
         _require_device(x2, logits2, W, bias)
         x2 = x2.contiguous()
@@ -535,6 +550,7 @@ class _RoutedLinear(torch.autograd.Function):
         return out, r["ids"]
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, d_out, _d_ids):
         x2, W, Y, ids, gate, offsets, perm = ctx.saved_tensors
         k, x_div, weighted, outer, E, has_bias = ctx.cfg
@@ -585,6 +601,7 @@ class _AgentAttn(torch.autograd.Function):
     """qkv (B,T,3*h*d) with the reference's '(qkv h d)' column order -> o (B,T,h*d)."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, qkv2, conv_w, conv_b, H, D, P, scale):
         _require_device(qkv2, conv_w, conv_b)
         B, T, _ = qkv2.shape
@@ -608,6 +625,7 @@ class _AgentAttn(torch.autograd.Function):
         return o.permute(0, 2, 1, 3).reshape(B, T, H * D)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, d_o2):
         qkv2, cw, agents, vagent, stats1 = ctx.saved_tensors
         H, D, P, scale = ctx.cfg
@@ -670,14 +688,22 @@ class _GEGLU(_SwiGLU):
     FWD, BWD = "amk_geglu_fwd", "amk_geglu_bwd"
 
 
+def _f32_outside_autocast(fn, x):
+    """(the gate Functions are classmethod-based: no custom_fwd; under autocast the input is upcast here)"""
+    if torch.is_autocast_enabled():
+        with torch.autocast("cuda", enabled=False):
+            return fn(x.float())
+    return fn(x)
+
+
 def swiglu(ab):
     """silu(a) * b for ab = (..., 2H) = (a | b): one HBM pass forward, one backward."""
-    return _SwiGLU.apply(ab)
+    return _f32_outside_autocast(_SwiGLU.apply, ab)
 
 
 def geglu(ab):
     """gelu(a) * b for ab = (..., 2H) = (a | b) (exact erf GELU): the transformer FFN gate."""
-    return _GEGLU.apply(ab)
+    return _f32_outside_autocast(_GEGLU.apply, ab)
 
 
 # ---------------------------------------------------------------------------- residual + LayerNorm
@@ -698,6 +724,7 @@ def _ln_backward(dy, h, dh_in, weight, mean, rstd):
 
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, weight, bias, eps):
         _require_device(x, weight, bias)
         D = x.shape[-1]
@@ -715,6 +742,7 @@ class _LayerNorm(torch.autograd.Function):
         return y.view(x.shape)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dy):
         x2, w, mean, rstd = ctx.saved_tensors
         dx, dw, db = _ln_backward(dy.contiguous().view(x2.shape), x2, None, w, mean, rstd)
@@ -725,6 +753,7 @@ class _AddLayerNorm(torch.autograd.Function):
     """(x, res) -> (h, y) with h = x + res, y = LN(h); the gradient of h is added inside the LN backward."""
 
     @staticmethod
+    @_amp_fwd
     def forward(ctx, x, res, weight, bias, eps):
         _require_device(x, res, weight, bias)
         D = x.shape[-1]
@@ -745,6 +774,7 @@ class _AddLayerNorm(torch.autograd.Function):
         return h.view(x.shape), y.view(x.shape)
 
     @staticmethod
+    @_amp_bwd
     def backward(ctx, dh_in, dy):
         h, w, mean, rstd = ctx.saved_tensors
         if dy is None:  # y unused downstream: only the residual stream carries gradient
@@ -867,6 +897,8 @@ class _LinearX6(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None):
+    if torch.is_autocast_enabled():  # mixed precision: the library GEMM in the autocast dtype, bias gradient by autograd
+        return torch.nn.functional.linear(x, weight, bias)
     if GEMM_MODE == "bf16x6" and _x6_ok(x, weight):
         return _LinearX6.apply(x, weight, bias)
     if bias is None:
