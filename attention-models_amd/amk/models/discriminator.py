@@ -83,6 +83,8 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         if self.groups != 1 or self.dilation != (1, 1) or self.padding_mode != "zeros" or isinstance(self.padding, str):
             return super().forward(x)
+        if torch.is_autocast_enabled():  # mixed precision: ATen's own convolution autograd (dtype handling included)
+            return super().forward(x)
         return _Conv.apply(x, self.weight, self.bias, self.stride, self.padding)
 
 

@@ -44,8 +44,12 @@ class VQGANTrainStep:
     def __init__(self, model, discr, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0,
                  adv_loss_weight=0.1, logit_laplace_weight=1.0, max_grad_norm=1.0,
                  warmup_steps=50000, decay_steps=100000, gp_lambda=10.0, bucket_bytes=32 << 20,
-                 share_forward=False, capturable=False, fused_optimizer=None):
+                 share_forward=False, capturable=False, fused_optimizer=None, autocast=None):
         self.model, self.discr = model, discr
+        # autocast: None (f32, the parity mode) or a dtype (torch.bfloat16): the forward passes and losses of both phases
+        # run inside torch.autocast as the reference's do (trainers/vitgqgan.py:149,168 `accelerator.autocast()`);
+        # parameters, gradients and optimizer state stay f32
+        self.autocast = autocast
         self.adv_w, self.laplace_w = adv_loss_weight, logit_laplace_weight
         self.max_grad_norm, self.gp_lambda = max_grad_norm, gp_lambda
         self.base_lr, self.warmup_steps, self.decay_steps = lr, warmup_steps, decay_steps
@@ -79,6 +83,13 @@ class VQGANTrainStep:
         # shipped config), one generator forward less.  Off by default: the step then mirrors the
         # reference call for call.
         self.share_forward = bool(share_forward)
+
+    def _amp(self):
+        import contextlib
+
+        if self.autocast is None:
+            return contextlib.nullcontext()
+        return torch.autocast("cuda", dtype=self.autocast)
 
     def gradient_penalty(self, real, fake, eta=None):
         """trainers/vitgqgan.py:115-131.  eta: the interpolation weights (drawn here unless given)."""
@@ -131,9 +142,10 @@ class VQGANTrainStep:
             set_requires_grad(model, False)
         set_requires_grad(discr, True)
         self.d_red.begin(sync)
-        if rec is None:
-            rec, _ = model(img)
-        d_loss = hinge_d_loss(discr(rec), discr(img)) + self.gradient_penalty(img, rec, eta)
+        with self._amp():
+            if rec is None:
+                rec, _ = model(img)
+            d_loss = hinge_d_loss(discr(rec), discr(img)) + self.gradient_penalty(img, rec, eta)
         (d_loss if accum_steps == 1 else d_loss / accum_steps).backward()
         self.d_red.finish()
         if sync:
@@ -146,11 +158,12 @@ class VQGANTrainStep:
         set_requires_grad(model, True)
         set_requires_grad(discr, False)
         self.g_red.begin(sync)
-        rec, codebook_loss = shared if shared is not None else model(img)
-        l1 = F.l1_loss(rec, img)
-        l2 = F.mse_loss(rec, img)
-        g_loss = g_nonsaturating_loss(discr(rec))
-        loss = codebook_loss + self.adv_w * g_loss + self.laplace_w * l1 + l2
+        with self._amp():
+            rec, codebook_loss = shared if shared is not None else model(img)
+            l1 = F.l1_loss(rec, img)
+            l2 = F.mse_loss(rec, img)
+            g_loss = g_nonsaturating_loss(discr(rec))
+            loss = codebook_loss + self.adv_w * g_loss + self.laplace_w * l1 + l2
         (loss if accum_steps == 1 else loss / accum_steps).backward()
         self.g_red.finish()
         if sync:
@@ -163,7 +176,8 @@ class VQGANTrainStep:
         shared = None
         if self.share_forward:
             set_requires_grad(self.model, True)
-            shared = self.model(img)
+            with self._amp():
+                shared = self.model(img)
         d_loss = self.d_phase(img, sync, accum_steps, eta, rec=shared[0].detach() if shared is not None else None)
         logs = self.g_phase(img, sync, accum_steps, shared)
         logs["d_loss"] = d_loss

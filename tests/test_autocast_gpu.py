@@ -53,3 +53,32 @@ def test_bf16_tensors_are_refused_outside_autocast(device):
     q = torch.randn(1, 2, 64, 64, device=device, dtype=torch.bfloat16)
     with pytest.raises(RuntimeError, match="fp32"):
         ops.attention(q, q, q, 0.125)
+
+
+def test_train_step_under_bf16_autocast(device):
+    """One GAN step with both phases' forwards under bf16 autocast (the reference's accelerator.autocast blocks):
+    losses finite and within mixed-precision distance of the f32 step, parameters updated and still f32."""
+    import copy
+
+    from amk.models import ViTVQGAN
+    from amk.models.discriminator import NLayerDiscriminator
+    from amk.train import VQGANTrainStep
+
+    torch.manual_seed(0)
+    vit = dict(dim=128, img_size=64, patch_size=8, n_heads=2, d_head=64, depth=2, mlp_dim=256, dropout=0.0)
+    model = ViTVQGAN(vit, dict(codebook_size=512, codebook_dim=32)).to(device)
+    discr = NLayerDiscriminator(3, 16, 3).to(device)
+    model2, discr2 = copy.deepcopy(model), copy.deepcopy(discr)
+    img = torch.rand(4, 3, 64, 64, device=device)
+    eta = torch.rand(4, 1, 1, 1, device=device)
+    ref = VQGANTrainStep(model, discr).step(img, eta=eta)
+    before = {n: p.detach().clone() for n, p in model2.named_parameters()}
+    got = VQGANTrainStep(model2, discr2, autocast=torch.bfloat16).step(img, eta=eta)
+    for key in ("d_loss", "g_loss", "l1", "l2", "codebook_loss"):
+        a, b = float(got[key]), float(ref[key])
+        assert a == a and abs(a - b) <= 0.05 * max(abs(b), 0.1), (key, a, b)
+    moved = 0
+    for n, p in model2.named_parameters():
+        assert p.dtype == torch.float32 and torch.isfinite(p).all()
+        moved += int(not torch.equal(p, before[n]))
+    assert moved > 0

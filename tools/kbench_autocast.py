@@ -1,7 +1,10 @@
 """ViT-VQGAN generator forward + backward (bench configuration, batch 32): f32 against torch.autocast(bf16) -- the
 reference's shipped mixed-precision setting (cfg/vitvqgan.yaml:73).  The attention / VQ / LayerNorm / gate kernels
 stay f32 under autocast (amk.ops upcasts their inputs); the nn.Linear GEMMs run in bf16.
-    python tools/kbench_autocast.py [--batch 32]
+    python tools/kbench_autocast.py [--batch 32] [--step]
+--step: the whole GAN train step of bench.py with both phases' forwards under bf16 autocast, as the reference's
+accelerator.autocast() blocks run them (about a minute of MIOpen searches for the bf16 convolutions first, which is why
+this is a tool and not a variant of the default bench run).
 """
 import argparse
 import os
@@ -19,6 +22,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--step", action="store_true")
     a = ap.parse_args()
     from amk import tuning
     from amk.models import ViTVQGAN
@@ -42,5 +46,25 @@ if __name__ == "__main__":
     t32 = time_launches(step(False), a.iters)
     t16 = time_launches(step(True), a.iters)
     l32, l16 = float(step(False)()), float(step(True)())
+    if a.step:
+        import time
+
+        from amk.models.discriminator import NLayerDiscriminator
+        from amk.train import VQGANTrainStep
+
+        tuning.enable_conv_autotune(True)
+        tr = VQGANTrainStep(model, NLayerDiscriminator(3, 64, 3).to(dev), autocast=torch.bfloat16)
+        t0 = time.time()
+        for _ in range(3):
+            logs = tr.step(img)
+        torch.cuda.synchronize()
+        print(f"train step under bf16 autocast: warm-up {time.time() - t0:.0f} s, losses "
+              + ", ".join(f"{k} {float(v):.4f}" for k, v in logs.items()), flush=True)
+        t0 = time.time()
+        for _ in range(a.iters):
+            tr.step(img)
+        torch.cuda.synchronize()
+        dt = (time.time() - t0) / a.iters
+        print(f"train step under bf16 autocast, batch {a.batch}: {dt * 1e3:.1f} ms = {a.batch / dt:.0f} images/s")
     print(f"generator fwd+bwd, batch {a.batch}: f32 {t32*1e3:.1f} ms ({a.batch/t32:.0f} images/s), bf16 autocast {t16*1e3:.1f} ms "
           f"({a.batch/t16:.0f} images/s); loss {l32:.5f} vs {l16:.5f}")
