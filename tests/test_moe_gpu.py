@@ -168,12 +168,13 @@ def test_switchhead_vs_oracle(device, B, T, dim, h, E, k):
             assert_close_abs(got[n], g, TOL, n)
 
 
-def test_routing_properties_full_size(device):
-    """At U = 64*65*8 units (ViTMoE batch 64): perm is a permutation, grouped by expert with
-    ascending pair index inside each expert, offsets match a histogram of ids, gates = sigmoid."""
+@pytest.mark.parametrize("U,E,k", [(64 * 65 * 8, 32, 2), (3000, 1024, 8), (1500, 100, 3), (70, 5, 1), (5000, 64, 4)])
+def test_routing_properties_full_size(device, U, E, k):
+    """At U = 64*65*8 units (ViTMoE batch 64) and at the limits of the routing kernels (1024 experts, top-8; partial
+    blocks): perm is a permutation, grouped by expert with ascending pair index inside each expert, offsets match a
+    histogram of ids, gates = sigmoid."""
     from amk import ops
 
-    U, E, k = 64 * 65 * 8, 32, 2
     g = torch.Generator().manual_seed(3)
     logits = torch.randn(U, E, generator=g).to(device)
     r = ops.moe_route(logits, k)
