@@ -20,6 +20,22 @@ _I = _c.c_int
 _L = _c.c_int64
 _F = _c.c_float
 
+
+
+class GemmDesc(_c.Structure):
+    """amk_gemm_desc of include/amk.h (field for field)."""
+    _fields_ = [("op", _c.c_int32), ("epilogue", _c.c_int32), ("m", _L),
+                ("n", _c.c_int32), ("k", _c.c_int32), ("split", _c.c_int32), ("reserved", _c.c_int32),
+                ("a", _P), ("a2", _P), ("w", _P), ("w2", _P), ("c", _P), ("c2", _P),
+                ("lda", _L), ("lda2", _L), ("ldw", _L), ("ldw2", _L), ("ldc", _L), ("ldc2", _L),
+                ("bias", _P), ("bias2", _P), ("resid", _P), ("ldr", _L),
+                ("ln_mean", _P), ("ln_rstd", _P), ("ln_gamma", _P), ("ln_beta", _P),
+                ("ab", _P), ("ldab", _L), ("gate", _P), ("ldg", _L), ("dbias", _P)]
+
+
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BIAS, EPI_RESID, EPI_SWIGLU, EPI_SWIGLU_BWD = 0, 1, 2, 3
+
 # name -> (restype, argtypes); mirrors include/amk.h one to one (tests/test_abi.py checks it).
 SIGNATURES = {
     "amk_version": (_I, []),
@@ -57,6 +73,9 @@ SIGNATURES = {
     "amk_gemm_x6_planes_bytes": (_L, [_I, _I]),
     "amk_gemm_x6_split": (_I, [_P, _L, _I, _I, _P, _P]),
     "amk_gemm_x6_nt": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P]),
+    "amk_gemm_f32_ws_bytes": (_L, [_c.POINTER(GemmDesc)]),
+    "amk_gemm_f32": (_I, [_c.POINTER(GemmDesc), _P, _L, _P]),
+    "amk_row_stats": (_I, [_P, _L, _I, _F, _P, _P, _P]),
     "amk_sample_step": (_I, [_P, _P, _F, _P, _c.c_uint64, _c.c_uint64, _F, _L, _I, _I, _P, _F, _P, _P, _P]),
     "amk_moe_route_ws_ints": (_L, [_L, _I, _I]),
     "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 8),

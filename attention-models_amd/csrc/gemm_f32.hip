@@ -1,0 +1,743 @@
+// Dense exact-f32 GEMMs for the nn.Linear layers around the attention core and the FFN, with the element-wise
+// passes that surround them folded into operand staging and epilogues (SURVEY.md section 8f rank 1;
+// reference: models/softmax_attention.py:30-42,80 -- q / kv / W_o projections --, models/vitvqgan.py:20-61 --
+// pre-LN, SwiGLU FFN, residual adds).  Three products, all on v_mfma_f32_32x32x2_f32 (exact f32, the same
+// rounding as an fmaf chain):
+//   NT  C[m, n]  = sum_k A'[m, k] W[n, k] (+ bias[n]) (+ R[m, n])      F.linear; A' = A or LayerNorm(A) applied
+//                                                                      while the tile is staged (mean / rstd given)
+//       SwiGLU epilogue: W = w12 (2H, K); the tile pairs gate column j with column H + j and writes
+//                        g = silu(a) * b (and (a | b) when the backward will need it)
+//   NN  C[m, n]  = sum_k A[m, k] W[k, n]                               input gradient dX = dY W, the contraction cut
+//                                                                      into two (A, W) segments (dq | dkv)
+//       SwiGLU-backward epilogue: the tile is dG; it reads (a | b) and writes (dA | dB)
+//   TN  C[n, k]  = sum_m Y[m, n] X'[m, k]                              weight gradient dW = dY^T X (X' = X or
+//                                                                      LayerNorm(X)), bias gradient = column sums of
+//                                                                      Y, the contraction (the M rows) cut into
+//                                                                      chunks whose partial tiles are summed in order
+// Tile: 128 x 128 outputs x 32 deep, four waves as 2 x 2, 64 x 64 per wave (four 32x32 accumulators); two
+// workgroups per CU.  Pipeline (as the expert GEMMs of moe.hip): two LDS stages, ONE barrier per step; during the
+// MFMAs of step t every thread moves its eight 16-byte pieces of tile t+1 from registers to the other stage and
+// refills them with tile t+2 through raw buffer loads (range-checked by the hardware: rows past the matrix read
+// as zeros, no compares); no branch around a vector-memory instruction, so every wait is a counted one.
+// Operand tiles come in two LDS images: "R" = [row][32 contraction values] (row stride 36 floats, read as
+// ds_read_b128: four MFMA steps per read) and "C" = [32 contraction rows][128 columns] (row stride 132, read as
+// ds_read_b32, consecutive lanes on consecutive columns).  MFMA step (s4, x) of lane half hf contracts index
+// 16 hf + 4 s4 + x of the 32 -- the same for both operands, any order of the contraction is as good as another.
+#include "amk_common.h"
+
+namespace amk_dense {
+
+constexpr int BK = 32;
+constexpr int LSR = 36;
+constexpr int LSC = 132;
+constexpr int STAGE = 2 * 128 * LSR;  // floats per stage: operand A region, then operand B region (each <= 128 * LSR)
+constexpr int BREG = 128 * LSR;
+constexpr unsigned ROW_PAST = 0x40000000u;  // added to an offset: beyond every buffer (records < 1 GiB)
+constexpr unsigned K_PAST = 0x80000000u;    // ROW_PAST + K_PAST + offset does not wrap
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ float4 bload4(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float bload1(__amdgpu_buffer_rsrc_t r, int off) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void bstore1(float v, __amdgpu_buffer_rsrc_t r, int off) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrsrc(const void* base, int64_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < 0 ? 0 : (bytes > 0x3FFFFFFF ? 0x3FFFFFFF : bytes)), 0x00020000);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+enum { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_SWIGLU_BWD = 3 };
+
+struct Params {
+  // operands (meaning per product, see the kernels)
+  const float *a, *a2, *w, *w2, *bias, *bias2, *resid;
+  float *c, *c2;
+  const float *ln_mean, *ln_rstd, *ln_gamma, *ln_beta;
+  const float* ab;   // SwiGLU backward: the forward's (a | b), (M, 2H)
+  float* gate;       // SwiGLU forward: g (M, H)
+  float* dbias;      // TN: bias-gradient partials / output
+  float* ws;         // TN: partial tiles (chunks, N, K)
+  int64_t lda, lda2, ldw, ldw2, ldc, ldc2, ldr, ldab, ldg;
+  int64_t M;
+  int N, K, split, H;
+  int ntn, total;    // column tiles per row tile, workgroups
+  int nchunk, steps_per_chunk;  // TN
+};
+
+// ---- the step loop shared by the three products -------------------------------------------------------------
+// ACT / BCT: the A / B operand tile is a "C" image.  a_rd / b_rd: this lane's read base inside a stage;
+// a_blk / b_blk: distance between the wave's two 32-wide blocks of that operand.
+// mv(i, nxt, kt): move piece i (0..7) of tile kt+1 from registers into stage `nxt`, then load piece i of tile kt+2.
+template <bool ACT, bool BCT, class Mover>
+__device__ __forceinline__ void step_loop(f32x16 (&acc)[2][2], float* smem, int nk, int a_rd, int a_blk, int b_rd,
+                                          int b_blk, Mover& mv) {
+  for (int kt = 0; kt < nk; ++kt) {
+    const float* cur = smem + (kt & 1) * STAGE;
+    float* nxt = smem + ((kt + 1) & 1) * STAGE;
+    float a[2][4], b[2][4];
+    auto frag = [&](int s4, float (&fa)[2][4], float (&fb)[2][4]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        if constexpr (!ACT) {
+          const float4 v = ld4(cur + a_rd + i * a_blk + 4 * s4);
+          fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) fa[i][x] = cur[a_rd + i * a_blk + (4 * s4 + x) * LSC];
+        }
+        if constexpr (!BCT) {
+          const float4 v = ld4(cur + BREG + b_rd + i * b_blk + 4 * s4);
+          fb[i][0] = v.x; fb[i][1] = v.y; fb[i][2] = v.z; fb[i][3] = v.w;
+        } else {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) fb[i][x] = cur[BREG + b_rd + i * b_blk + (4 * s4 + x) * LSC];
+        }
+      }
+    };
+    frag(0, a, b);
+#pragma unroll
+    for (int s4 = 0; s4 < 4; ++s4) {
+      float an[2][4], bn[2][4];
+      if (s4 + 1 < 4) frag(s4 + 1, an, bn);
+      mv(2 * s4, nxt, kt);
+      mv(2 * s4 + 1, nxt, kt);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i][x], b[j][x], acc[i][j]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (s4 + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { a[i][x] = an[i][x]; b[i][x] = bn[i][x]; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// =============================================================================================================
+// NT: C = A' W^T.  A (M, K) "R" image, W (N, K) "R" image.
+// Column segments: output columns [0, split) use (w, bias, c), columns [split, N) use (w2, bias2, c2) with their
+// own leading dimensions -- q and kv projections in one launch (split a multiple of 128; 0 = one segment).
+// SwiGLU: W = w12 (2H, K), N = H; tile nt covers gate columns [64 nt, 64 nt + 64): LDS rows [0, 64) = rows j of
+// W, rows [64, 128) = rows H + j.
+template <int EPI, bool LNA>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int u = xcd_remap(blockIdx.x, p.total);
+  const int mt = u / p.ntn, nt = u - mt * p.ntn;
+  const int64_t m0 = (int64_t)mt * 128;
+  const int rows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
+  constexpr bool SW = EPI == EPI_SWIGLU;
+  // this tile's column segment
+  int n0 = SW ? nt * 64 : nt * 128;
+  const bool seg = !SW && p.split > 0 && n0 >= p.split;
+  const float* Wb = seg ? p.w2 : p.w;
+  const float* bias = seg ? p.bias2 : p.bias;
+  float* Cb = seg ? p.c2 : p.c;
+  const int64_t ldw = seg ? p.ldw2 : p.ldw, ldc = seg ? p.ldc2 : p.ldc;
+  const int ncols = SW ? p.H : (p.split > 0 ? (seg ? p.N - p.split : p.split) : p.N);
+  if (seg) n0 -= p.split;
+  const int wrows = SW ? 2 * p.H : ncols;
+
+  const int sr = tid >> 3, sc = (tid & 7) * 4;
+  const __amdgpu_buffer_rsrc_t a_rsrc = mkrsrc(p.a + m0 * p.lda, ((int64_t)(rows - 1) * p.lda + p.K) * 4);
+  const __amdgpu_buffer_rsrc_t w_rsrc = mkrsrc(Wb, ((int64_t)(wrows - 1) * ldw + p.K) * 4);
+  const __amdgpu_buffer_rsrc_t g_rsrc = mkrsrc(LNA ? p.ln_gamma : p.a, LNA ? (int64_t)p.K * 4 : 0);
+  const __amdgpu_buffer_rsrc_t be_rsrc = mkrsrc(LNA ? p.ln_beta : p.a, LNA ? (int64_t)p.K * 4 : 0);
+  unsigned goff[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) goff[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda + sc) * 4);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int rr = sr + 32 * j;  // LDS row of the W region
+    int wr;                      // row of W
+    bool ok;
+    if (SW) { const int jj = n0 + (rr & 63); ok = jj < p.H; wr = (rr < 64 ? 0 : p.H) + jj; }
+    else { wr = n0 + rr; ok = wr < ncols; }
+    goff[4 + j] = ok ? (unsigned)(((int64_t)wr * ldw + sc) * 4) : ROW_PAST;
+  }
+  float rs[4], mu[4];
+  if (LNA) {
+    const __amdgpu_buffer_rsrc_t m_rsrc = mkrsrc(p.ln_mean + m0, (int64_t)rows * 4);
+    const __amdgpu_buffer_rsrc_t r_rsrc = mkrsrc(p.ln_rstd + m0, (int64_t)rows * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { mu[j] = bload1(m_rsrc, (sr + 32 * j) * 4); rs[j] = bload1(r_rsrc, (sr + 32 * j) * 4); }
+  }
+  float4 stg[8], gam, bet;
+  const int nk = (p.K + BK - 1) / BK;
+  auto kadd = [&](int kt) {
+    const int k0 = (kt < nk ? kt : nk - 1) * BK;
+    return (k0 + sc < p.K) ? (unsigned)(k0 * 4) : K_PAST;
+  };
+  auto gload = [&](int i, unsigned ka) {
+    if (i < 4) stg[i] = bload4(a_rsrc, (int)(goff[i] + ka));
+    else stg[i] = bload4(w_rsrc, (int)(goff[i] + ka));
+  };
+  auto lstore = [&](int i, float* stage) {
+    float4 v = stg[i];
+    if (LNA && i < 4) {
+      v.x = fmaf((v.x - mu[i]) * rs[i], gam.x, bet.x); v.y = fmaf((v.y - mu[i]) * rs[i], gam.y, bet.y);
+      v.z = fmaf((v.z - mu[i]) * rs[i], gam.z, bet.z); v.w = fmaf((v.w - mu[i]) * rs[i], gam.w, bet.w);
+    }
+    st4(&stage[(i < 4 ? 0 : BREG) + (sr + 32 * (i & 3)) * LSR + sc], v);
+  };
+  auto gbload = [&](unsigned ka) {  // gamma / beta of a tile's 4 columns (zeros past K: the K tail stays zero)
+    if (LNA) { gam = bload4(g_rsrc, (int)(ka + sc * 4)); bet = bload4(be_rsrc, (int)(ka + sc * 4)); }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+
+  unsigned ka = kadd(0);
+  gbload(ka);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload(i, ka);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lstore(i, smem);
+  ka = kadd(1);
+  gbload(ka);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload(i, ka);
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered in the state its back edge leaves
+  __syncthreads();
+
+  unsigned ka2 = 0;
+  auto mv = [&](int i, float* nxt, int kt) {
+    if (i == 0) ka2 = kadd(kt + 2);
+    lstore(i, nxt);
+    if (i == 3) gbload(ka2);  // the A pieces of tile kt+1 are stored: their gamma / beta registers are free
+    gload(i, ka2);
+  };
+  const int a_rd = (64 * wm + ln) * LSR + 16 * hf;
+  const int b_rd = ((SW ? 32 : 64) * wn + ln) * LSR + 16 * hf;
+  step_loop<false, false>(acc, smem, nk, a_rd, 32 * LSR, b_rd, (SW ? 64 : 32) * LSR, mv);
+
+  // ---- epilogue
+  const int row0 = 64 * wm + 4 * hf;
+  if (SW) {
+    const int j = n0 + 32 * wn + ln;
+    const bool ok = j < p.H;
+    const float ba = (bias && ok) ? bias[j] : 0.f, bb = (bias && ok) ? bias[p.H + j] : 0.f;
+    const __amdgpu_buffer_rsrc_t gr = mkrsrc(p.gate + m0 * p.ldg, ((int64_t)(rows - 1) * p.ldg + p.H) * 4);
+    const __amdgpu_buffer_rsrc_t abr = mkrsrc(Cb ? Cb + m0 * ldc : p.gate, Cb ? ((int64_t)(rows - 1) * ldc + 2 * p.H) * 4 : 0);
+    const unsigned cg = ok ? (unsigned)j * 4u : K_PAST;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+        const float av = acc[i][0][r] + ba, bv = acc[i][1][r] + bb;
+        bstore1(av * sigmoidf_(av) * bv, gr, (int)((unsigned)(row * p.ldg * 4) + cg));
+        if (Cb) {
+          bstore1(av, abr, (int)((unsigned)(row * ldc * 4) + cg));
+          bstore1(bv, abr, (int)((unsigned)(row * ldc * 4) + cg + (unsigned)p.H * 4u));
+        }
+      }
+    }
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t cr = mkrsrc(Cb + m0 * ldc, ((int64_t)(rows - 1) * ldc + ncols) * 4);
+  const __amdgpu_buffer_rsrc_t rr = mkrsrc(EPI == EPI_RESID ? p.resid + m0 * p.ldr : p.a, EPI == EPI_RESID ? ((int64_t)(rows - 1) * p.ldr + ncols) * 4 : 0);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + 64 * wn + 32 * j + ln;
+    const bool ok = n < ncols;
+    const float bv = (bias && ok) ? bias[n] : 0.f;
+    const unsigned cn = ok ? (unsigned)n * 4u : K_PAST;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float res[16];
+      if (EPI == EPI_RESID) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+          res[r] = bload1(rr, (int)((unsigned)(row * p.ldr * 4) + cn));
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+        float v = acc[i][j][r] + bv;
+        if (EPI == EPI_RESID) v += res[r];
+        bstore1(v, cr, (int)((unsigned)(row * ldc * 4) + cn));
+      }
+    }
+  }
+}
+
+// =============================================================================================================
+// NN: C[m, n] = sum_k A[m, k] W[k, n].  A (M, K) "R" image, W (K, N) "C" image.
+// Contraction segments: k in [0, split) reads (a, w), k in [split, K) reads (a2, w2) at k - split (split = 0: one).
+// SwiGLU backward: N = H, the tile is dG; c = (dA | dB) (M, 2H), ab = the forward's (a | b).
+template <int EPI>
+__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int u = xcd_remap(blockIdx.x, p.total);
+  const int mt = u / p.ntn, nt = u - mt * p.ntn;
+  const int64_t m0 = (int64_t)mt * 128;
+  const int rows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
+  const int n0 = nt * 128;
+  const int K0 = p.split > 0 ? p.split : p.K, K1 = p.K - K0;
+  const int nk0 = (K0 + BK - 1) / BK, nk1 = (K1 + BK - 1) / BK, nk = nk0 + nk1;
+
+  const int sr = tid >> 3, sc = (tid & 7) * 4;   // A pieces: rows sr + 32 j, 4 floats at column sc
+  const int cr = tid >> 5, cc = (tid & 31) * 4;  // W pieces: contraction rows cr + 8 j, 4 floats at column cc
+  const bool col_ok = n0 + cc < p.N;
+  // byte offsets of this thread's pieces inside the row panel of A / the slab of W, per contraction segment
+  unsigned aoff0[4], aoff1[4], woff0[4], woff1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    aoff0[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda + sc) * 4);
+    aoff1[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda2 + sc) * 4);
+    woff0[j] = col_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw + n0 + cc) * 4) : ROW_PAST;
+    woff1[j] = col_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw2 + n0 + cc) * 4) : ROW_PAST;
+  }
+  float4 stg[8];
+  // segment state of the tile being loaded (wave-uniform)
+  auto seg_of = [&](int kt, int& s, int& k0) {
+    const int t = kt < nk ? kt : nk - 1;
+    s = t >= nk0;
+    k0 = (s ? t - nk0 : t) * BK;
+  };
+  auto gload_tile_piece = [&](int i, int s, int k0) {
+    const float* ab_ = s ? p.a2 : p.a;
+    const int64_t lda = s ? p.lda2 : p.lda;
+    const float* wb_ = s ? p.w2 : p.w;
+    const int64_t ldw = s ? p.ldw2 : p.ldw;
+    const int Ks = s ? K1 : K0;
+    if (i < 4) {
+      const __amdgpu_buffer_rsrc_t ar = mkrsrc(ab_ + m0 * lda, ((int64_t)(rows - 1) * lda + Ks) * 4);
+      const unsigned off = (k0 + sc < Ks) ? (s ? aoff1[i] : aoff0[i]) + (unsigned)(k0 * 4) : K_PAST;
+      stg[i] = bload4(ar, (int)off);
+    } else {
+      const __amdgpu_buffer_rsrc_t wr = mkrsrc(wb_, ((int64_t)(Ks - 1) * ldw + p.N) * 4);
+      stg[i] = bload4(wr, (int)((s ? woff1[i - 4] : woff0[i - 4]) + (unsigned)(k0 * ldw * 4)));
+    }
+  };
+  auto lstore = [&](int i, float* stage) {
+    if (i < 4) st4(&stage[(sr + 32 * i) * LSR + sc], stg[i]);
+    else st4(&stage[BREG + (cr + 8 * (i - 4)) * LSC + cc], stg[i]);
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  int s, k0;
+  seg_of(0, s, k0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload_tile_piece(i, s, k0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lstore(i, smem);
+  seg_of(1, s, k0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload_tile_piece(i, s, k0);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  int s2 = 0, k2 = 0;
+  auto mv = [&](int i, float* nxt, int kt) {
+    if (i == 0) seg_of(kt + 2, s2, k2);
+    lstore(i, nxt);
+    gload_tile_piece(i, s2, k2);
+  };
+  const int a_rd = (64 * wm + ln) * LSR + 16 * hf;
+  const int b_rd = (16 * hf) * LSC + 64 * wn + ln;
+  step_loop<false, true>(acc, smem, nk, a_rd, 32 * LSR, b_rd, 32, mv);
+
+  const int row0 = 64 * wm + 4 * hf;
+  if (EPI == EPI_SWIGLU_BWD) {
+    const __amdgpu_buffer_rsrc_t abr = mkrsrc(p.ab + m0 * p.ldab, ((int64_t)(rows - 1) * p.ldab + 2 * p.H) * 4);
+    const __amdgpu_buffer_rsrc_t cr_ = mkrsrc(p.c + m0 * p.ldc, ((int64_t)(rows - 1) * p.ldc + 2 * p.H) * 4);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + 64 * wn + 32 * j + ln;
+      const unsigned cn = n < p.H ? (unsigned)n * 4u : K_PAST;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        float av[16], bv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+          av[r] = bload1(abr, (int)((unsigned)(row * p.ldab * 4) + cn));
+          bv[r] = bload1(abr, (int)((unsigned)(row * p.ldab * 4) + cn + (unsigned)p.H * 4u));
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+          const float g = acc[i][j][r], sg = sigmoidf_(av[r]);
+          bstore1(g * bv[r] * (sg * (1.f + av[r] * (1.f - sg))), cr_, (int)((unsigned)(row * p.ldc * 4) + cn));
+          bstore1(g * (av[r] * sg), cr_, (int)((unsigned)(row * p.ldc * 4) + cn + (unsigned)p.H * 4u));
+        }
+      }
+    }
+    return;
+  }
+  const __amdgpu_buffer_rsrc_t cr_ = mkrsrc(p.c + m0 * p.ldc, ((int64_t)(rows - 1) * p.ldc + p.N) * 4);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = n0 + 64 * wn + 32 * j + ln;
+    const unsigned cn = n < p.N ? (unsigned)n * 4u : K_PAST;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+        bstore1(acc[i][j][r], cr_, (int)((unsigned)(row * p.ldc * 4) + cn));
+      }
+    }
+  }
+}
+
+// =============================================================================================================
+// TN: C[n, k] = sum_m Y[m, n] X'[m, k]; Y (M, N) and X (M, K) both "C" images (the contraction is the row index).
+// Row segments of the output: n in [0, split) reads Y = a (lda) and writes c; n in [split, N) reads a2 (lda2) and
+// writes c2 (dq | dkv).  X = w (ldw), optionally LayerNorm(X) (mean / rstd per row m, gamma / beta per column k).
+// The M rows are cut into nchunk chunks of steps_per_chunk 32-row steps; with nchunk > 1 every workgroup writes its
+// partial tile to ws[chunk] (chunks, N, K) and tn_reduce_kernel sums the chunks in order.  dbias (column sums of
+// Y) is accumulated by the workgroups of the first k tile from the pieces they stage.
+template <bool LNX>
+__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Params p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  // unit = (tile, chunk), chunks of one tile adjacent; tiles [n tile][k tile]
+  const int u = xcd_remap(blockIdx.x, p.total);
+  const int tile = u / p.nchunk, chunk = u - tile * p.nchunk;
+  const int ntk = p.ntn;  // k tiles per n tile
+  const int tn = tile / ntk, tk = tile - tn * ntk;
+  int n0 = tn * 128;
+  const int k0t = tk * 128;
+  const bool seg = p.split > 0 && n0 >= p.split;
+  const float* Yb = seg ? p.a2 : p.a;
+  const int64_t ldy = seg ? p.lda2 : p.lda;
+  const int nrows = p.split > 0 ? (seg ? p.N - p.split : p.split) : p.N;  // rows of this segment's output
+  if (seg) n0 -= p.split;
+  const int64_t mbeg = (int64_t)chunk * p.steps_per_chunk * BK;
+  int64_t mend = mbeg + (int64_t)p.steps_per_chunk * BK;
+  if (mend > p.M) mend = p.M;
+  const int mrows = (int)(mend - mbeg);
+  const int nk = (mrows + BK - 1) / BK;
+
+  const int cr = tid >> 5, cc = (tid & 31) * 4;
+  const __amdgpu_buffer_rsrc_t y_rsrc = mkrsrc(Yb + mbeg * ldy, ((int64_t)(mrows - 1) * ldy + nrows) * 4);
+  const __amdgpu_buffer_rsrc_t x_rsrc = mkrsrc(p.w + mbeg * p.ldw, ((int64_t)(mrows - 1) * p.ldw + p.K) * 4);
+  const __amdgpu_buffer_rsrc_t m_rsrc = mkrsrc(LNX ? p.ln_mean + mbeg : p.a, LNX ? (int64_t)mrows * 4 : 0);
+  const __amdgpu_buffer_rsrc_t r_rsrc = mkrsrc(LNX ? p.ln_rstd + mbeg : p.a, LNX ? (int64_t)mrows * 4 : 0);
+  const bool ycol_ok = n0 + cc < nrows, xcol_ok = k0t + cc < p.K;
+  unsigned goff[8];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    goff[j] = ycol_ok ? (unsigned)(((int64_t)(cr + 8 * j) * ldy + n0 + cc) * 4) : ROW_PAST;
+    goff[4 + j] = xcol_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw + k0t + cc) * 4) : ROW_PAST;
+  }
+  const unsigned ystep = (unsigned)(BK * ldy * 4), xstep = (unsigned)(BK * p.ldw * 4);
+  float4 gam = make_float4(0.f, 0.f, 0.f, 0.f), bet = gam;
+  if (LNX && xcol_ok) { gam = ld4(p.ln_gamma + k0t + cc); bet = ld4(p.ln_beta + k0t + cc); }
+  float4 stg[8];
+  float mu[4], rs[4];
+  float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+  const bool do_bias = p.dbias != nullptr && tk == 0;
+  auto gload = [&](int i, int kt) {  // (rows past the chunk: past the descriptor, zeros)
+    const int t = kt < nk ? kt : nk - 1;
+    if (i < 4) stg[i] = bload4(y_rsrc, (int)(goff[i] + (unsigned)t * ystep));
+    else {
+      stg[i] = bload4(x_rsrc, (int)(goff[i] + (unsigned)t * xstep));
+      if (LNX) {
+        mu[i - 4] = bload1(m_rsrc, (t * BK + cr + 8 * (i - 4)) * 4);
+        rs[i - 4] = bload1(r_rsrc, (t * BK + cr + 8 * (i - 4)) * 4);
+      }
+    }
+  };
+  auto lstore = [&](int i, float* stage, bool count) {
+    float4 v = stg[i];
+    if (i < 4) {
+      if (do_bias && count) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
+      st4(&stage[(cr + 8 * i) * LSC + cc], v);
+    } else {
+      if (LNX) {
+        const float m_ = mu[i - 4], r_ = rs[i - 4];
+        v.x = fmaf((v.x - m_) * r_, gam.x, bet.x); v.y = fmaf((v.y - m_) * r_, gam.y, bet.y);
+        v.z = fmaf((v.z - m_) * r_, gam.z, bet.z); v.w = fmaf((v.w - m_) * r_, gam.w, bet.w);
+      }
+      st4(&stage[BREG + (cr + 8 * (i - 4)) * LSC + cc], v);
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload(i, 0);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) lstore(i, smem, true);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) gload(i, 1);
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+  auto mv = [&](int i, float* nxt, int kt) {
+    lstore(i, nxt, kt + 1 < nk);  // (the re-read tile past the end is stored, never used, and not counted)
+    gload(i, kt + 2);
+  };
+  const int a_rd = (16 * hf) * LSC + 64 * wm + ln;
+  const int b_rd = (16 * hf) * LSC + 64 * wn + ln;
+  step_loop<true, true>(acc, smem, nk, a_rd, 32, b_rd, 32, mv);
+
+  // ---- epilogue: the partial tile
+  float* Cb;
+  int64_t ldc;
+  if (p.nchunk > 1) { Cb = p.ws + ((int64_t)chunk * p.N + (seg ? p.split : 0)) * p.K; ldc = p.K; }
+  else { Cb = seg ? p.c2 : p.c; ldc = seg ? p.ldc2 : p.ldc; }
+  const int orow = nrows - n0 < 128 ? nrows - n0 : 128;  // valid rows of the tile
+  const __amdgpu_buffer_rsrc_t c_rsrc = mkrsrc(Cb + (int64_t)n0 * ldc, ((int64_t)(orow - 1) * ldc + p.K) * 4);
+  const int row0 = 64 * wm + 4 * hf;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int kcol = k0t + 64 * wn + 32 * j + ln;
+    const unsigned cn = kcol < p.K ? (unsigned)kcol * 4u : K_PAST;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
+        bstore1(acc[i][j][r], c_rsrc, (int)((unsigned)(row * ldc * 4) + cn));
+      }
+    }
+  }
+  if (do_bias) {  // fold the eight row groups (cr) of each column quad
+    float* red = smem;  // (the step loop ended with a barrier)
+    st4(&red[cr * 128 + cc], bsum);
+    __syncthreads();
+    if (tid < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += red[j * 128 + tid];
+      const int n = n0 + tid;
+      if (n < nrows) p.dbias[(int64_t)(p.nchunk > 1 ? chunk : 0) * p.N + (seg ? p.split : 0) + n] = s;
+    }
+  }
+}
+
+// C = sum over chunks of ws (in chunk order).  Elements [0, split * K) go to c (rows of ldc), the rest to c2.
+__global__ __launch_bounds__(256) void tn_reduce_kernel(Params p, float* dbias_out) {
+  const int64_t total4 = (int64_t)p.N * p.K / 4;
+  const int64_t slab = (int64_t)p.N * p.K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+    float4 s = ld4(p.ws + 4 * i);
+    for (int c = 1; c < p.nchunk; ++c) {
+      const float4 v = ld4(p.ws + c * slab + 4 * i);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int64_t e = 4 * i;
+    int64_t row = e / p.K;
+    const int col = (int)(e - row * p.K);
+    if (p.split > 0 && row >= p.split) st4(p.c2 + (row - p.split) * p.ldc2 + col, s);
+    else st4(p.c + row * p.ldc + col, s);
+  }
+  if (dbias_out && blockIdx.x == 0) {
+    for (int n = threadIdx.x; n < p.N; n += 256) {
+      float s = 0.f;
+      for (int c = 0; c < p.nchunk; ++c) s += p.dbias[(int64_t)c * p.N + n];
+      dbias_out[n] = s;
+    }
+  }
+}
+
+// mean / rstd of every row (two-pass form, as add_layernorm_fwd): one wave per row, D <= 4096
+template <int NCH>
+__global__ __launch_bounds__(256) void row_stats_kernel(const float* __restrict__ x, int64_t M, int D, float eps,
+                                                        float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = D >> 2;
+  const float inv_d = 1.f / (float)D;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      v[j] = c < nch ? ld4(x + row * D + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      s += v[j].x + v[j].y + v[j].z + v[j].w;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s * inv_d;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+      const int c = lane + 64 * j;
+      if (c < nch) {
+        const float a = v[j].x - mean, b = v[j].y - mean, cc = v[j].z - mean, d = v[j].w - mean;
+        q += a * a + b * b + cc * cc + d * d;
+      }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rsqrtf(q * inv_d + eps); }
+  }
+}
+
+}  // namespace amk_dense
+
+using namespace amk_dense;
+
+static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+static int tn_chunks(const amk_gemm_desc* d, int* steps_per_chunk) {
+  const int tiles = ((d->n + 127) / 128) * ((d->k + 127) / 128);
+  const int64_t steps = (d->m + BK - 1) / BK;
+  int64_t chunks = 512 / tiles;  // workgroup slots of the chip (two per CU) over the tiles
+  if (chunks < 1) chunks = 1;
+  if (chunks > steps / 8) chunks = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps per chunk
+  int64_t spc = (steps + chunks - 1) / chunks;
+  chunks = (steps + spc - 1) / spc;
+  *steps_per_chunk = (int)spc;
+  return (int)chunks;
+}
+
+extern "C" int64_t amk_gemm_f32_ws_bytes(const amk_gemm_desc* d) {
+  if (!d || d->op != AMK_GEMM_TN) return 0;
+  int spc;
+  const int chunks = tn_chunks(d, &spc);
+  if (chunks <= 1) return 0;
+  return ((int64_t)chunks * d->n * d->k + (int64_t)chunks * d->n) * 4;
+}
+
+extern "C" int amk_row_stats(const float* x, int64_t M, int D, float eps, float* mean, float* rstd, void* stream) {
+  AMK_CHECK_ARG(x && mean && rstd, "amk_row_stats: null pointer");
+  AMK_CHECK_ARG(M > 0 && D > 0, "amk_row_stats: non-positive size");
+  AMK_CHECK_SUPPORTED(D % 4 == 0 && D <= 4096 && a16(x), "amk_row_stats: D %% 4 == 0, D <= 4096 and a 16-byte aligned pointer required");
+  const int64_t blocks = (M + 3) / 4;
+  const dim3 grid((unsigned)(blocks < 16384 ? blocks : 16384));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (D <= 256) hipLaunchKernelGGL(row_stats_kernel<1>, grid, dim3(256), 0, st, x, M, D, eps, mean, rstd);
+  else if (D <= 1024) hipLaunchKernelGGL(row_stats_kernel<4>, grid, dim3(256), 0, st, x, M, D, eps, mean, rstd);
+  else hipLaunchKernelGGL(row_stats_kernel<16>, grid, dim3(256), 0, st, x, M, D, eps, mean, rstd);
+  AMK_CHECK_LAUNCH("amk_row_stats");
+  return AMK_OK;
+}
+
+extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_bytes, void* stream) {
+  AMK_CHECK_ARG(d, "amk_gemm_f32: null descriptor");
+  const bool c_optional = d->op == AMK_GEMM_NT && d->epilogue == AMK_EPI_SWIGLU;  // (a | b) is written only on request
+  AMK_CHECK_ARG(d->a && d->w && (d->c || c_optional), "amk_gemm_f32: null operand");
+  AMK_CHECK_ARG(d->m > 0 && d->n > 0 && d->k > 0, "amk_gemm_f32: non-positive size");
+  const bool two = d->split > 0;
+  AMK_CHECK_SUPPORTED(d->k % 4 == 0 && d->lda % 4 == 0 && d->ldw % 4 == 0 && d->ldc % 4 == 0 && a16(d->a) && a16(d->w) && a16(d->c),
+                      "amk_gemm_f32: K and leading dimensions must be multiples of 4, pointers 16-byte aligned");
+  AMK_CHECK_SUPPORTED(d->m < (int64_t)1 << 31, "amk_gemm_f32: M too large");
+  const int64_t lim = (int64_t)1 << 30;  // operand panels are addressed through 32-bit buffer offsets
+  Params p = {};
+  p.a = d->a; p.a2 = d->a2; p.w = d->w; p.w2 = d->w2; p.bias = d->bias; p.bias2 = d->bias2; p.resid = d->resid;
+  p.c = d->c; p.c2 = d->c2;
+  p.ln_mean = d->ln_mean; p.ln_rstd = d->ln_rstd; p.ln_gamma = d->ln_gamma; p.ln_beta = d->ln_beta;
+  p.ab = d->ab; p.gate = d->gate;
+  p.lda = d->lda; p.lda2 = d->lda2; p.ldw = d->ldw; p.ldw2 = d->ldw2; p.ldc = d->ldc; p.ldc2 = d->ldc2;
+  p.ldr = d->ldr; p.ldab = d->ldab; p.ldg = d->ldg;
+  p.M = d->m; p.N = d->n; p.K = d->k; p.split = d->split; p.H = d->n;
+  const bool ln = d->ln_mean != nullptr;
+  if (ln) AMK_CHECK_ARG(d->ln_rstd && d->ln_gamma && d->ln_beta, "amk_gemm_f32: LayerNorm operand needs mean, rstd, gamma and beta");
+  if (two) {
+    AMK_CHECK_ARG(d->split < (d->op == AMK_GEMM_NN ? d->k : d->n), "amk_gemm_f32: split outside the segmented axis");
+    AMK_CHECK_SUPPORTED(d->split % 128 == 0 || d->op == AMK_GEMM_NN, "amk_gemm_f32: output split must be a multiple of 128");
+    AMK_CHECK_SUPPORTED(d->op != AMK_GEMM_NN || d->split % 4 == 0, "amk_gemm_f32: contraction split must be a multiple of 4");
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t mt = (d->m + 127) / 128;
+  if (d->op == AMK_GEMM_NT) {
+    const bool sw = d->epilogue == AMK_EPI_SWIGLU;
+    if (two) AMK_CHECK_ARG(!sw && d->w2 && d->c2 && d->ldw2 % 4 == 0 && d->ldc2 % 4 == 0, "amk_gemm_f32: second column segment incomplete");
+    AMK_CHECK_SUPPORTED(128 * d->lda * 4 < lim && (int64_t)(sw ? 2 : 1) * d->n * d->ldw * 4 < lim && 128 * d->ldc * 4 < lim,
+                        "amk_gemm_f32: operand panel beyond 1 GiB");
+    if (sw) AMK_CHECK_ARG(d->gate && d->ldg % 4 == 0, "amk_gemm_f32: SwiGLU epilogue needs the gate output");
+    if (d->epilogue == AMK_EPI_RESID) AMK_CHECK_ARG(d->resid && !two && d->ldr % 4 == 0, "amk_gemm_f32: residual epilogue needs resid (one column segment)");
+    p.ntn = sw ? (d->n + 63) / 64 : (two ? d->split / 128 + (d->n - d->split + 127) / 128 : (d->n + 127) / 128);
+    const int64_t total = mt * p.ntn;
+    AMK_CHECK_SUPPORTED(total < (int64_t)1 << 31, "amk_gemm_f32: grid too large");
+    p.total = (int)total;
+    const dim3 grid((unsigned)total), blk(256);
+#define AMK_NT(E, L) hipLaunchKernelGGL((gemm_nt_kernel<E, L>), grid, blk, 0, st, p)
+    if (sw) { if (ln) AMK_NT(EPI_SWIGLU, true); else AMK_NT(EPI_SWIGLU, false); }
+    else if (d->epilogue == AMK_EPI_RESID) { if (ln) AMK_NT(EPI_RESID, true); else AMK_NT(EPI_RESID, false); }
+    else if (d->epilogue == AMK_EPI_BIAS) { if (ln) AMK_NT(EPI_BIAS, true); else AMK_NT(EPI_BIAS, false); }
+    else AMK_CHECK_ARG(false, "amk_gemm_f32: epilogue %d is not an NT epilogue", d->epilogue);
+#undef AMK_NT
+    AMK_CHECK_LAUNCH("amk_gemm_f32(NT)");
+    return AMK_OK;
+  }
+  if (d->op == AMK_GEMM_NN) {
+    const bool swb = d->epilogue == AMK_EPI_SWIGLU_BWD;
+    if (two) AMK_CHECK_ARG(d->a2 && d->w2 && d->lda2 % 4 == 0 && d->ldw2 % 4 == 0, "amk_gemm_f32: second contraction segment incomplete");
+    AMK_CHECK_SUPPORTED(d->n % 4 == 0, "amk_gemm_f32(NN): N must be a multiple of 4");
+    AMK_CHECK_SUPPORTED(128 * d->lda * 4 < lim && (int64_t)d->k * d->ldw * 4 < lim && 128 * d->ldc * 4 < lim &&
+                        (!two || (128 * d->lda2 * 4 < lim && (int64_t)d->k * d->ldw2 * 4 < lim)),
+                        "amk_gemm_f32: operand panel beyond 1 GiB");
+    if (swb) AMK_CHECK_ARG(d->ab && d->ldab % 4 == 0 && 128 * d->ldab * 4 < lim, "amk_gemm_f32: SwiGLU backward epilogue needs (a | b)");
+    else AMK_CHECK_ARG(d->epilogue == AMK_EPI_BIAS && !d->bias, "amk_gemm_f32(NN): epilogue must be AMK_EPI_BIAS without a bias, or AMK_EPI_SWIGLU_BWD");
+    p.ntn = (d->n + 127) / 128;
+    const int64_t total = mt * p.ntn;
+    AMK_CHECK_SUPPORTED(total < (int64_t)1 << 31, "amk_gemm_f32: grid too large");
+    p.total = (int)total;
+    if (swb) hipLaunchKernelGGL((gemm_nn_kernel<EPI_SWIGLU_BWD>), dim3((unsigned)total), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_nn_kernel<EPI_BIAS>), dim3((unsigned)total), dim3(256), 0, st, p);
+    AMK_CHECK_LAUNCH("amk_gemm_f32(NN)");
+    return AMK_OK;
+  }
+  AMK_CHECK_ARG(d->op == AMK_GEMM_TN, "amk_gemm_f32: unknown op %d", d->op);
+  if (two) AMK_CHECK_ARG(d->a2 && d->c2 && d->lda2 % 4 == 0 && d->ldc2 % 4 == 0, "amk_gemm_f32: second row segment incomplete");
+  AMK_CHECK_SUPPORTED(d->n % 4 == 0 && (!two || (d->n - d->split) % 4 == 0), "amk_gemm_f32(TN): N must be a multiple of 4");
+  int spc;
+  const int chunks = tn_chunks(d, &spc);
+  AMK_CHECK_SUPPORTED((int64_t)spc * BK * d->lda * 4 < lim && (int64_t)spc * BK * d->ldw * 4 < lim && (!two || (int64_t)spc * BK * d->lda2 * 4 < lim),
+                      "amk_gemm_f32(TN): chunk panel beyond 1 GiB");
+  AMK_CHECK_SUPPORTED((int64_t)d->n * d->k * 4 < lim, "amk_gemm_f32(TN): output beyond 1 GiB");
+  if (chunks > 1) {
+    AMK_CHECK_ARG(workspace && ws_bytes >= amk_gemm_f32_ws_bytes(d), "amk_gemm_f32(TN): workspace of amk_gemm_f32_ws_bytes() bytes required");
+    AMK_CHECK_ARG(a16(workspace), "amk_gemm_f32(TN): workspace must be 16-byte aligned");
+    p.ws = static_cast<float*>(workspace);
+  }
+  p.nchunk = chunks;
+  p.steps_per_chunk = spc;
+  p.ntn = (d->k + 127) / 128;
+  float* dbias_out = d->dbias;
+  p.dbias = d->dbias ? (chunks > 1 ? p.ws + (int64_t)chunks * d->n * d->k : d->dbias) : nullptr;
+  const int64_t total = (int64_t)((d->n + 127) / 128) * p.ntn * chunks;
+  if (two) AMK_CHECK_ARG(d->split % 128 == 0, "amk_gemm_f32(TN): split must be a multiple of 128");
+  p.total = (int)total;
+  if (ln) hipLaunchKernelGGL((gemm_tn_kernel<true>), dim3((unsigned)total), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_tn_kernel<false>), dim3((unsigned)total), dim3(256), 0, st, p);
+  AMK_CHECK_LAUNCH("amk_gemm_f32(TN)");
+  if (chunks > 1) {
+    const int64_t items = (int64_t)d->n * d->k / 4;
+    const int64_t blocks = (items + 255) / 256;
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, p, dbias_out);
+    AMK_CHECK_LAUNCH("amk_gemm_f32(TN reduce)");
+  }
+  return AMK_OK;
+}

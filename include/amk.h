@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 121 /* 0.2.0: kept attention scores (amk_attn_fwd_keep / amk_attn_bwd_kept), 256-key backward workgroups */
+#define AMK_VERSION 130 /* 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
 
 enum {
   AMK_OK = 0,
@@ -421,6 +421,60 @@ int64_t amk_gemm_x6_planes_bytes(int N, int K);
 int amk_gemm_x6_split(const float* W, int64_t ldw, int N, int K, void* planes, void* stream);
 int amk_gemm_x6_nt(const float* A, int64_t lda, const void* w_planes, const float* bias,
                    float* C, int64_t ldc, int M, int N, int K, void* stream);
+
+/* --------------------------------------------------------------------------
+ * Dense exact-f32 GEMMs with the surrounding element-wise passes folded in.
+ * Replaces, around the attention core and in the FFN of the ViT-VQGAN blocks, nn.Linear forward / backward
+ * (models/softmax_attention.py:30-42,80; models/vitvqgan.py:20-34) together with nn.LayerNorm applied to its
+ * input (models/vitvqgan.py:44-48), the residual add behind it (:50-61), the SwiGLU gate between w12 and w3 and
+ * the bias gradients.  All operands f32 row-major; products on v_mfma_f32_32x32x2_f32 (exact f32).
+ *
+ *   op AMK_GEMM_NT   C[m, n] = sum_k A'[m, k] W[n, k] (+ bias[n]) (+ resid[m, n])        F.linear(A', W, bias)
+ *        A (m x k, lda), W (n x k, ldw), C (m x n, ldc).  A' = ((A - ln_mean[m]) * ln_rstd[m]) * ln_gamma[k] +
+ *        ln_beta[k] when ln_mean != NULL (LayerNorm applied while the tile is staged), else A.
+ *        split > 0: output columns [split, n) use (w2, ldw2, bias2, c2, ldc2) instead -- two projections of the
+ *        same input in one launch; split a multiple of 128.
+ *        epilogue AMK_EPI_BIAS, AMK_EPI_RESID (adds resid (m x n, ldr); resid may be c itself), or
+ *        AMK_EPI_SWIGLU: W is w12 (2n x k), bias (2n) or NULL; gate[m, j] = silu(a) * b with a = column j,
+ *        b = column n + j of A' W^T + bias; gate (m x n, ldg) is written, and c (m x 2n, ldc) = (a | b) too
+ *        unless c == NULL.
+ *   op AMK_GEMM_NN   C[m, n] = sum_k A[m, k] W[k, n]                                     dX = dY W
+ *        A (m x k, lda), W (k x n, ldw).  split > 0: contraction indices [split, k) read (a2, lda2) column
+ *        k - split and (w2, ldw2) row k - split.
+ *        epilogue AMK_EPI_BIAS (bias must be NULL: plain store), or AMK_EPI_SWIGLU_BWD: the product is dGate
+ *        (m x n); ab (m x 2n, ldab) is the forward's (a | b); c (m x 2n, ldc) = (dA | dB) =
+ *        (dGate * b * silu'(a) | dGate * silu(a)).
+ *   op AMK_GEMM_TN   C[n, k] = sum_m Y[m, n] X'[m, k]                                    dW = dY^T X', db = colsum(dY)
+ *        a = Y (m x n, lda), w = X (m x k, ldw), c (n x k, ldc); X' = LayerNorm(X) as above when ln_mean != NULL
+ *        (ln_gamma / ln_beta indexed by k).  split > 0: output rows [split, n) read Y = (a2, lda2) column
+ *        n - split and are written to (c2, ldc2); split a multiple of 128.  dbias (n) != NULL: column sums of Y.
+ *        The m rows are cut into chunks; partial tiles go through `workspace` (amk_gemm_f32_ws_bytes(d) bytes,
+ *        16-byte aligned) and are summed in chunk order: bitwise reproducible.
+ * k and every leading dimension multiples of 4, pointers 16-byte aligned, operand panels below 1 GiB.
+ * amk_row_stats: mean and rstd = 1 / sqrt(var + eps) (biased variance, two-pass) of every row of x (M x D),
+ * the statistics nn.LayerNorm uses; D a multiple of 4, at most 4096.
+ * -------------------------------------------------------------------------- */
+enum { AMK_GEMM_NT = 0, AMK_GEMM_NN = 1, AMK_GEMM_TN = 2 };
+enum { AMK_EPI_BIAS = 0, AMK_EPI_RESID = 1, AMK_EPI_SWIGLU = 2, AMK_EPI_SWIGLU_BWD = 3 };
+typedef struct amk_gemm_desc {
+  int32_t op, epilogue;
+  int64_t m;
+  int32_t n, k, split, reserved;
+  const float *a, *a2, *w, *w2;
+  float *c, *c2;
+  int64_t lda, lda2, ldw, ldw2, ldc, ldc2;
+  const float *bias, *bias2, *resid;
+  int64_t ldr;
+  const float *ln_mean, *ln_rstd, *ln_gamma, *ln_beta;
+  const float* ab;
+  int64_t ldab;
+  float* gate;
+  int64_t ldg;
+  float* dbias;
+} amk_gemm_desc;
+int64_t amk_gemm_f32_ws_bytes(const amk_gemm_desc* d);
+int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_bytes, void* stream);
+int amk_row_stats(const float* x, int64_t M, int D, float eps, float* mean, float* rstd, void* stream);
 
 #ifdef __cplusplus
 }
