@@ -19,7 +19,13 @@ from bench import time_launches  # noqa: E402
 PEAK = 157.3
 
 
+CHECK = True
+
+
 def err(x, ref):
+    if not CHECK:
+        return 0.0
+    ref = ref() if callable(ref) else ref
     return float((x.double() - ref).abs().max() / ref.abs().max())
 
 
@@ -27,7 +33,11 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--only", default="", help="comma-separated shape names")
+    ap.add_argument("--no-fused", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the float64 error columns (PMC runs)")
     a = ap.parse_args()
+    CHECK = not a.no_check
     from amk import dense, ops, tuning
 
     tuning.enable_gemm_tuning()
@@ -38,13 +48,15 @@ if __name__ == "__main__":
     shapes = [("q", 256, 512), ("kv", 256, 1024), ("W_o", 512, 256), ("ffn w12", 256, 2736), ("ffn w3", 1368, 256),
               ("patch embed", 192, 256), ("pre_quant", 256, 32), ("post_quant", 32, 256), ("fc", 256, 192)]
     tot = dict(lib_nt=0.0, amk_nt=0.0, lib_nn=0.0, amk_nn=0.0, lib_tn=0.0, amk_tn=0.0)
+    if a.only:
+        shapes = [s for s in shapes if s[0].replace(" ", "_") in a.only.split(",")]
     for name, K, N in shapes:
         x, w, b, dy = rnd(M, K), rnd(N, K) * K ** -0.5, rnd(N), rnd(M, N)
         fl = 2.0 * M * N * K
         # forward
         t_lib = time_launches(lambda: F.linear(x, w, b), a.iters)
         t_amk = time_launches(lambda: dense.gemm_nt(x, w, b), a.iters)
-        ref = x.double() @ w.double().t() + b.double()
+        ref = (x.double() @ w.double().t() + b.double()) if CHECK else None
         e_lib, e_amk = err(F.linear(x, w, b), ref), err(dense.gemm_nt(x, w, b), ref)
         tot["lib_nt"] += t_lib; tot["amk_nt"] += t_amk
         print(f"NT {name:12s} K{K:5d} N{N:5d}  lib {t_lib*1e6:7.1f} us {fl/t_lib/1e12:6.1f} TF err {e_lib:.1e} | "
@@ -53,7 +65,7 @@ if __name__ == "__main__":
         if N % 4 == 0:
             t_lib = time_launches(lambda: dy.mm(w), a.iters)
             t_amk = time_launches(lambda: dense.gemm_nn(dy, w), a.iters)
-            ref = dy.double() @ w.double()
+            ref = (dy.double() @ w.double()) if CHECK else None
             e_lib, e_amk = err(dy.mm(w), ref), err(dense.gemm_nn(dy, w), ref)
             tot["lib_nn"] += t_lib; tot["amk_nn"] += t_amk
             print(f"NN {name:12s} K{N:5d} N{K:5d}  lib {t_lib*1e6:7.1f} us {fl/t_lib/1e12:6.1f} TF err {e_lib:.1e} | "
@@ -61,15 +73,17 @@ if __name__ == "__main__":
             # weight gradient + bias gradient
             t_lib = time_launches(lambda: (dy.t().mm(x), ops.colsum(dy)), a.iters)
             t_amk = time_launches(lambda: dense.gemm_tn(dy, x, want_bias=True), a.iters)
-            ref = dy.double().t() @ x.double()
+            ref = (dy.double().t() @ x.double()) if CHECK else None
             dw, _, db = dense.gemm_tn(dy, x, want_bias=True)
             e_lib, e_amk = err(dy.t().mm(x), ref), err(dw, ref)
-            e_db = err(db, dy.double().sum(0))
+            e_db = err(db, lambda: dy.double().sum(0))
             tot["lib_tn"] += t_lib; tot["amk_tn"] += t_amk
             print(f"TN {name:12s} M{M} -> {N}x{K}  lib+colsum {t_lib*1e6:7.1f} us {fl/t_lib/1e12:6.1f} TF err {e_lib:.1e} | "
                   f"amk {t_amk*1e6:7.1f} us {fl/t_amk/1e12:6.1f} TF ({fl/t_amk/1e12/PEAK:.3f}) err {e_amk:.1e} db {e_db:.1e}  x{t_lib/t_amk:.2f}", flush=True)
     print("sums (ms): " + "  ".join(f"{k} {v*1e3:.3f}" for k, v in tot.items()), flush=True)
 
+    if a.no_fused:
+        sys.exit(0)
     # ---- fused forms against the launches they replace (one encoder layer's Linear + element-wise work)
     D, Hh, inner = 256, 1368, 512
     h = rnd(M, D)
