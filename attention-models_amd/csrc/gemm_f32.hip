@@ -14,26 +14,41 @@
 //                                                                      LayerNorm(X)), bias gradient = column sums of
 //                                                                      Y, the contraction (the M rows) cut into
 //                                                                      chunks whose partial tiles are summed in order
-// Tile: 128 x 128 outputs x 32 deep, four waves as 2 x 2, 64 x 64 per wave (four 32x32 accumulators); two
-// workgroups per CU.  Pipeline (as the expert GEMMs of moe.hip): two LDS stages, ONE barrier per step; during the
-// MFMAs of step t every thread moves its eight 16-byte pieces of tile t+1 from registers to the other stage and
+// Tile: 128 x 128 outputs x BK deep (BK = 16 or 32), four waves as 2 x 2, 64 x 64 per wave (four 32x32
+// accumulators).  Pipeline (as the expert GEMMs of moe.hip): two LDS stages, ONE barrier per step; during the
+// MFMAs of step t every thread moves its 16-byte pieces of tile t+1 from registers to the other stage and
 // refills them with tile t+2 through raw buffer loads (range-checked by the hardware: rows past the matrix read
 // as zeros, no compares); no branch around a vector-memory instruction, so every wait is a counted one.
-// Operand tiles come in two LDS images: "R" = [row][32 contraction values] (row stride 36 floats, read as
-// ds_read_b128: four MFMA steps per read) and "C" = [32 contraction rows][128 columns] (row stride 132, read as
+// Operand tiles come in two LDS images: "R" = [row][BK contraction values] (row stride BK + 4 floats, read as
+// ds_read_b128: four MFMA steps per read) and "C" = [BK contraction rows][128 columns] (row stride 132, read as
 // ds_read_b32, consecutive lanes on consecutive columns).  MFMA step (s4, x) of lane half hf contracts index
-// 16 hf + 4 s4 + x of the 32 -- the same for both operands, any order of the contraction is as good as another.
+// (BK / 2) hf + 4 s4 + x of the BK -- the same for both operands, any order of the contraction is as good as another.
 #include "amk_common.h"
+#include <stdlib.h>
+#include <string.h>
+
+#ifndef AMK_DENSE_DEFAULT_BK
+#define AMK_DENSE_DEFAULT_BK 32
+#endif
 
 namespace amk_dense {
 
-constexpr int BK = 32;
-constexpr int LSR = 36;
 constexpr int LSC = 132;
-constexpr int STAGE = 2 * 128 * LSR;  // floats per stage: operand A region, then operand B region (each <= 128 * LSR)
-constexpr int BREG = 128 * LSR;
 constexpr unsigned ROW_PAST = 0x40000000u;  // added to an offset: beyond every buffer (records < 1 GiB)
 constexpr unsigned K_PAST = 0x80000000u;    // ROW_PAST + K_PAST + offset does not wrap
+
+template <int BK>
+struct Geo {
+  static constexpr int LSR = BK + 4;
+  static constexpr int BREG = 128 * LSR;         // operand A region, then operand B region (each <= 128 * LSR floats)
+  static constexpr int STAGE = 2 * BREG;
+  static constexpr int NG = BK / 8;              // MFMA groups (16 MFMA each) per step
+  static constexpr int NP = BK / 8;              // 16-byte pieces per operand, thread and step
+  static constexpr int TPR = BK / 4;             // threads per row of an "R" image
+  static constexpr int RPP = 256 / TPR;          // rows per pass of an "R" image
+  static_assert(BK == 16 || BK == 32, "BK");
+  static_assert(BK * LSC <= BREG, "the C image must fit the operand region");
+};
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
@@ -73,18 +88,60 @@ struct Params {
   int N, K, split, H;
   int ntn, total;    // column tiles per row tile, workgroups
   int nchunk, steps_per_chunk;  // TN
+  int stagger_mode, stagger_sleeps;  // see stagger()
 };
 
+// All workgroups of a launch start together and run tiles of equal length: the two (three) workgroups that share a
+// CU load their first tiles, and later store their results, at the same time, with nobody's MFMAs to cover it.
+// The workgroups of the first dispatch round that hold the "second" slot of a CU start a few microseconds late;
+// their successors inherit the offset.  mode 1: slot = bit 5 of the workgroup's index inside its XCD (CUs filled
+// breadth first); mode 2: bit 0 (depth first); mode 3: the XOR of both.
+__device__ __forceinline__ void stagger(const Params& p, int slots) {
+  if (p.stagger_mode == 0 || (int)blockIdx.x >= slots) return;
+  const int k = blockIdx.x >> 3;
+  const int late = p.stagger_mode == 1 ? (k >> 5) & 1 : (p.stagger_mode == 2 ? k & 1 : ((k >> 5) ^ k) & 1);
+  if (late) {
+    for (int i = 0; i < p.stagger_sleeps; ++i) __builtin_amdgcn_s_sleep(127);
+  }
+}
+
+// Epilogue addressing.  A lane's 16 values of a 32x32 accumulator are rows e + 8 q + 4 hf (e, q = 0..3) of one column:
+// per group of 8 rows (i, q) a descriptor of its own (scalar registers: base at the group's first row, records up to
+// the last VALID row of the group -- rows past the matrix are dropped by the range check) and four lane offsets
+// (rows 4 hf + e, the lane's column) shared by all groups: 4 vector registers per leading dimension instead of 32.
+__device__ __forceinline__ void lane_offsets(unsigned (&vo)[4], int hf, int64_t ld, unsigned colbytes) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) vo[e] = (unsigned)((4 * hf + e) * ld * 4) + colbytes;  // (colbytes may carry K_PAST)
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t group_rsrc(const float* base, int64_t ld, int rows, int rg0, int col0, int width) {
+  int n = rows - rg0;
+  n = n > 8 ? 8 : n;
+  return mkrsrc(base + (int64_t)rg0 * ld + col0, n > 0 ? ((int64_t)(n - 1) * ld + width) * 4 : 0);
+}
+
+// Instruction issue on a SIMD is arbitrated by priority, then age, and the f32 MFMA stream of the co-resident
+// workgroup leaves few slots: a wave that loads its first tiles or stores its results next to a partner in its tile
+// loop was measured at 5 us (prologue) and 13 us (epilogue) for a few hundred instructions.  Those two phases run at
+// priority 3 (they hold the pipe for a few cycles per instruction); the tile loop at AMK_DENSE_MOVE_PRIO around
+// its data movement and 0 around its MFMAs.
+#ifndef AMK_DENSE_EDGE_PRIO
+#define AMK_DENSE_EDGE_PRIO 3
+#endif
+#ifndef AMK_DENSE_MOVE_PRIO
+#define AMK_DENSE_MOVE_PRIO 0
+#endif
 // ---- the step loop shared by the three products -------------------------------------------------------------
 // ACT / BCT: the A / B operand tile is a "C" image.  a_rd / b_rd: this lane's read base inside a stage;
 // a_blk / b_blk: distance between the wave's two 32-wide blocks of that operand.
-// mv(i, nxt, kt): move piece i (0..7) of tile kt+1 from registers into stage `nxt`, then load piece i of tile kt+2.
-template <bool ACT, bool BCT, class Mover>
+// mv(i, nxt, kt): move piece i (0 .. 2 NP - 1) of tile kt+1 from registers into stage `nxt`, then load piece i of
+// tile kt+2.
+template <int BK, bool ACT, bool BCT, class Mover>
 __device__ __forceinline__ void step_loop(f32x16 (&acc)[2][2], float* smem, int nk, int a_rd, int a_blk, int b_rd,
                                           int b_blk, Mover& mv) {
+  using G = Geo<BK>;
   for (int kt = 0; kt < nk; ++kt) {
-    const float* cur = smem + (kt & 1) * STAGE;
-    float* nxt = smem + ((kt + 1) & 1) * STAGE;
+    const float* cur = smem + (kt & 1) * G::STAGE;
+    float* nxt = smem + ((kt + 1) & 1) * G::STAGE;
     float a[2][4], b[2][4];
     auto frag = [&](int s4, float (&fa)[2][4], float (&fb)[2][4]) {
 #pragma unroll
@@ -97,21 +154,36 @@ __device__ __forceinline__ void step_loop(f32x16 (&acc)[2][2], float* smem, int 
           for (int x = 0; x < 4; ++x) fa[i][x] = cur[a_rd + i * a_blk + (4 * s4 + x) * LSC];
         }
         if constexpr (!BCT) {
-          const float4 v = ld4(cur + BREG + b_rd + i * b_blk + 4 * s4);
+          const float4 v = ld4(cur + G::BREG + b_rd + i * b_blk + 4 * s4);
           fb[i][0] = v.x; fb[i][1] = v.y; fb[i][2] = v.z; fb[i][3] = v.w;
         } else {
 #pragma unroll
-          for (int x = 0; x < 4; ++x) fb[i][x] = cur[BREG + b_rd + i * b_blk + (4 * s4 + x) * LSC];
+          for (int x = 0; x < 4; ++x) fb[i][x] = cur[G::BREG + b_rd + i * b_blk + (4 * s4 + x) * LSC];
         }
       }
     };
-    frag(0, a, b);
+#ifndef AMK_ABLATE
+#define AMK_ABLATE 0
+#endif
+    if (!(AMK_ABLATE & 4) || kt == 0) frag(0, a, b);
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
+    for (int s4 = 0; s4 < G::NG; ++s4) {
       float an[2][4], bn[2][4];
-      if (s4 + 1 < 4) frag(s4 + 1, an, bn);
-      mv(2 * s4, nxt, kt);
-      mv(2 * s4 + 1, nxt, kt);
+      if (s4 + 1 < G::NG) {
+        if (!(AMK_ABLATE & 4)) frag(s4 + 1, an, bn);
+        else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { an[i][x] = a[i][x]; bn[i][x] = b[i][x]; }
+        }
+      }
+      if (AMK_DENSE_MOVE_PRIO) __builtin_amdgcn_s_setprio(AMK_DENSE_MOVE_PRIO);
+      if (!(AMK_ABLATE & 1)) {
+        mv(2 * s4, nxt, kt);
+        mv(2 * s4 + 1, nxt, kt);
+      }
+      if (AMK_DENSE_MOVE_PRIO) __builtin_amdgcn_s_setprio(0);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
@@ -122,7 +194,7 @@ __device__ __forceinline__ void step_loop(f32x16 (&acc)[2][2], float* smem, int 
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (s4 + 1 < 4) {
+      if (s4 + 1 < G::NG) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
 #pragma unroll
@@ -130,9 +202,11 @@ __device__ __forceinline__ void step_loop(f32x16 (&acc)[2][2], float* smem, int 
         }
       }
     }
-    __syncthreads();
+    if (!(AMK_ABLATE & 2)) __syncthreads();
   }
 }
+
+#define AMK_DENSE_BOUNDS(BK) __launch_bounds__(256, (BK) == 16 ? 3 : 2)
 
 // =============================================================================================================
 // NT: C = A' W^T.  A (M, K) "R" image, W (N, K) "R" image.
@@ -140,11 +214,25 @@ __device__ __forceinline__ void step_loop(f32x16 (&acc)[2][2], float* smem, int 
 // own leading dimensions -- q and kv projections in one launch (split a multiple of 128; 0 = one segment).
 // SwiGLU: W = w12 (2H, K), N = H; tile nt covers gate columns [64 nt, 64 nt + 64): LDS rows [0, 64) = rows j of
 // W, rows [64, 128) = rows H + j.
-template <int EPI, bool LNA>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Params p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+template <int BK, int EPI, bool LNA>
+__global__ AMK_DENSE_BOUNDS(BK) void gemm_nt_kernel(Params p) {
+  using G = Geo<BK>;
+  constexpr int NP = G::NP, LSR = G::LSR;
+  __shared__ __attribute__((aligned(16))) float smem[2 * G::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
+  stagger(p, (BK == 16 ? 3 : 2) * 256);
+  __builtin_amdgcn_s_setprio(AMK_DENSE_EDGE_PRIO);
+#ifdef AMK_DENSE_STAMPS
+#define AMK_STAMP(i) do { if (tid == 0 && p.ws) reinterpret_cast<unsigned long long*>(p.ws)[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+  AMK_STAMP(0);
+  if (tid == 0 && p.ws) {
+    reinterpret_cast<unsigned long long*>(p.ws)[(size_t)blockIdx.x * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_ID
+    reinterpret_cast<unsigned long long*>(p.ws)[(size_t)blockIdx.x * 8 + 7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // XCC_ID
+  }
+#else
+#define AMK_STAMP(i)
+#endif
   const int u = xcd_remap(blockIdx.x, p.total);
   const int mt = u / p.ntn, nt = u - mt * p.ntn;
   const int64_t m0 = (int64_t)mt * 128;
@@ -161,47 +249,47 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Params p) {
   if (seg) n0 -= p.split;
   const int wrows = SW ? 2 * p.H : ncols;
 
-  const int sr = tid >> 3, sc = (tid & 7) * 4;
+  const int sr = tid / G::TPR, sc = (tid % G::TPR) * 4;
   const __amdgpu_buffer_rsrc_t a_rsrc = mkrsrc(p.a + m0 * p.lda, ((int64_t)(rows - 1) * p.lda + p.K) * 4);
   const __amdgpu_buffer_rsrc_t w_rsrc = mkrsrc(Wb, ((int64_t)(wrows - 1) * ldw + p.K) * 4);
   const __amdgpu_buffer_rsrc_t g_rsrc = mkrsrc(LNA ? p.ln_gamma : p.a, LNA ? (int64_t)p.K * 4 : 0);
   const __amdgpu_buffer_rsrc_t be_rsrc = mkrsrc(LNA ? p.ln_beta : p.a, LNA ? (int64_t)p.K * 4 : 0);
-  unsigned goff[8];
+  unsigned goff[2 * NP];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) goff[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda + sc) * 4);
+  for (int j = 0; j < NP; ++j) goff[j] = (unsigned)(((int64_t)(sr + G::RPP * j) * p.lda + sc) * 4);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int rr = sr + 32 * j;  // LDS row of the W region
-    int wr;                      // row of W
+  for (int j = 0; j < NP; ++j) {
+    const int rr = sr + G::RPP * j;  // LDS row of the W region
+    int wr;                          // row of W
     bool ok;
     if (SW) { const int jj = n0 + (rr & 63); ok = jj < p.H; wr = (rr < 64 ? 0 : p.H) + jj; }
     else { wr = n0 + rr; ok = wr < ncols; }
-    goff[4 + j] = ok ? (unsigned)(((int64_t)wr * ldw + sc) * 4) : ROW_PAST;
+    goff[NP + j] = ok ? (unsigned)(((int64_t)wr * ldw + sc) * 4) : ROW_PAST;
   }
-  float rs[4], mu[4];
+  float rs[NP], mu[NP];
   if (LNA) {
     const __amdgpu_buffer_rsrc_t m_rsrc = mkrsrc(p.ln_mean + m0, (int64_t)rows * 4);
     const __amdgpu_buffer_rsrc_t r_rsrc = mkrsrc(p.ln_rstd + m0, (int64_t)rows * 4);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { mu[j] = bload1(m_rsrc, (sr + 32 * j) * 4); rs[j] = bload1(r_rsrc, (sr + 32 * j) * 4); }
+    for (int j = 0; j < NP; ++j) { mu[j] = bload1(m_rsrc, (sr + G::RPP * j) * 4); rs[j] = bload1(r_rsrc, (sr + G::RPP * j) * 4); }
   }
-  float4 stg[8], gam, bet;
+  float4 stg[2 * NP], gam, bet;
   const int nk = (p.K + BK - 1) / BK;
   auto kadd = [&](int kt) {
     const int k0 = (kt < nk ? kt : nk - 1) * BK;
     return (k0 + sc < p.K) ? (unsigned)(k0 * 4) : K_PAST;
   };
   auto gload = [&](int i, unsigned ka) {
-    if (i < 4) stg[i] = bload4(a_rsrc, (int)(goff[i] + ka));
+    if (i < NP) stg[i] = bload4(a_rsrc, (int)(goff[i] + ka));
     else stg[i] = bload4(w_rsrc, (int)(goff[i] + ka));
   };
   auto lstore = [&](int i, float* stage) {
     float4 v = stg[i];
-    if (LNA && i < 4) {
+    if (LNA && i < NP) {
       v.x = fmaf((v.x - mu[i]) * rs[i], gam.x, bet.x); v.y = fmaf((v.y - mu[i]) * rs[i], gam.y, bet.y);
       v.z = fmaf((v.z - mu[i]) * rs[i], gam.z, bet.z); v.w = fmaf((v.w - mu[i]) * rs[i], gam.w, bet.w);
     }
-    st4(&stage[(i < 4 ? 0 : BREG) + (sr + 32 * (i & 3)) * LSR + sc], v);
+    st4(&stage[(i < NP ? 0 : G::BREG) + (sr + G::RPP * (i % NP)) * LSR + sc], v);
   };
   auto gbload = [&](unsigned ka) {  // gamma / beta of a tile's 4 columns (zeros past K: the K tail stays zero)
     if (LNA) { gam = bload4(g_rsrc, (int)(ka + sc * 4)); bet = bload4(be_rsrc, (int)(ka + sc * 4)); }
@@ -215,89 +303,109 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(Params p) {
   unsigned ka = kadd(0);
   gbload(ka);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) gload(i, ka);
+  for (int i = 0; i < 2 * NP; ++i) gload(i, ka);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) lstore(i, smem);
+  for (int i = 0; i < 2 * NP; ++i) lstore(i, smem);
   ka = kadd(1);
   gbload(ka);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) gload(i, ka);
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): the loop is entered in the state its back edge leaves
+  for (int i = 0; i < 2 * NP; ++i) gload(i, ka);
   __syncthreads();
+  AMK_STAMP(1);
 
   unsigned ka2 = 0;
   auto mv = [&](int i, float* nxt, int kt) {
     if (i == 0) ka2 = kadd(kt + 2);
     lstore(i, nxt);
-    if (i == 3) gbload(ka2);  // the A pieces of tile kt+1 are stored: their gamma / beta registers are free
+    if (i == NP - 1) gbload(ka2);  // the A pieces of tile kt+1 are stored: their gamma / beta registers are free
     gload(i, ka2);
   };
-  const int a_rd = (64 * wm + ln) * LSR + 16 * hf;
-  const int b_rd = ((SW ? 32 : 64) * wn + ln) * LSR + 16 * hf;
-  step_loop<false, false>(acc, smem, nk, a_rd, 32 * LSR, b_rd, (SW ? 64 : 32) * LSR, mv);
+  const int a_rd = (64 * wm + ln) * LSR + (BK / 2) * hf;
+  const int b_rd = ((SW ? 32 : 64) * wn + ln) * LSR + (BK / 2) * hf;
+  __builtin_amdgcn_s_setprio(0);
+  step_loop<BK, false, false>(acc, smem, nk, a_rd, 32 * LSR, b_rd, (SW ? 64 : 32) * LSR, mv);
+  __builtin_amdgcn_s_setprio(AMK_DENSE_EDGE_PRIO);
+  AMK_STAMP(2);
 
   // ---- epilogue
-  const int row0 = 64 * wm + 4 * hf;
-  if (SW) {
+  if constexpr (SW) {
     const int j = n0 + 32 * wn + ln;
     const bool ok = j < p.H;
     const float ba = (bias && ok) ? bias[j] : 0.f, bb = (bias && ok) ? bias[p.H + j] : 0.f;
-    const __amdgpu_buffer_rsrc_t gr = mkrsrc(p.gate + m0 * p.ldg, ((int64_t)(rows - 1) * p.ldg + p.H) * 4);
-    const __amdgpu_buffer_rsrc_t abr = mkrsrc(Cb ? Cb + m0 * ldc : p.gate, Cb ? ((int64_t)(rows - 1) * ldc + 2 * p.H) * 4 : 0);
     const unsigned cg = ok ? (unsigned)j * 4u : K_PAST;
+    unsigned vg[4], vc[4];
+    lane_offsets(vg, hf, p.ldg, cg);
+    lane_offsets(vc, hf, ldc, cg);
+    const float* gbase = p.gate + m0 * p.ldg;
+    const float* abase = Cb ? Cb + m0 * ldc : p.gate;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
-        const float av = acc[i][0][r] + ba, bv = acc[i][1][r] + bb;
-        bstore1(av * sigmoidf_(av) * bv, gr, (int)((unsigned)(row * p.ldg * 4) + cg));
-        if (Cb) {
-          bstore1(av, abr, (int)((unsigned)(row * ldc * 4) + cg));
-          bstore1(bv, abr, (int)((unsigned)(row * ldc * 4) + cg + (unsigned)p.H * 4u));
+      for (int q = 0; q < 4; ++q) {
+        const int rg0 = 64 * wm + 32 * i + 8 * q;
+        const __amdgpu_buffer_rsrc_t gr = group_rsrc(gbase, p.ldg, rows, rg0, 0, p.H);
+        const __amdgpu_buffer_rsrc_t ar = group_rsrc(abase, ldc, Cb ? rows : 0, rg0, 0, p.H);
+        const __amdgpu_buffer_rsrc_t br = group_rsrc(abase, ldc, Cb ? rows : 0, rg0, p.H, p.H);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float av = acc[i][0][4 * q + e] + ba, bv = acc[i][1][4 * q + e] + bb;
+          bstore1(av * sigmoidf_(av) * bv, gr, (int)vg[e]);
+          if (Cb) { bstore1(av, ar, (int)vc[e]); bstore1(bv, br, (int)vc[e]); }
         }
       }
     }
     return;
   }
-  const __amdgpu_buffer_rsrc_t cr = mkrsrc(Cb + m0 * ldc, ((int64_t)(rows - 1) * ldc + ncols) * 4);
-  const __amdgpu_buffer_rsrc_t rr = mkrsrc(EPI == EPI_RESID ? p.resid + m0 * p.ldr : p.a, EPI == EPI_RESID ? ((int64_t)(rows - 1) * p.ldr + ncols) * 4 : 0);
+  const float* cbase = Cb + m0 * ldc;
+  const float* rbase = EPI == EPI_RESID ? p.resid + m0 * p.ldr : p.a;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + 64 * wn + 32 * j + ln;
     const bool ok = n < ncols;
     const float bv = (bias && ok) ? bias[n] : 0.f;
     const unsigned cn = ok ? (unsigned)n * 4u : K_PAST;
+    unsigned vo[4], vr[4];
+    lane_offsets(vo, hf, ldc, cn);
+    if (EPI == EPI_RESID) lane_offsets(vr, hf, p.ldr, cn);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       float res[16];
       if (EPI == EPI_RESID) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
-          res[r] = bload1(rr, (int)((unsigned)(row * p.ldr * 4) + cn));
+        for (int q = 0; q < 4; ++q) {
+          const __amdgpu_buffer_rsrc_t rr = group_rsrc(rbase, p.ldr, rows, 64 * wm + 32 * i + 8 * q, 0, ncols);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) res[4 * q + e] = bload1(rr, (int)vr[e]);
         }
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
-        float v = acc[i][j][r] + bv;
-        if (EPI == EPI_RESID) v += res[r];
-        bstore1(v, cr, (int)((unsigned)(row * ldc * 4) + cn));
+      for (int q = 0; q < 4; ++q) {
+        const __amdgpu_buffer_rsrc_t cr = group_rsrc(cbase, ldc, rows, 64 * wm + 32 * i + 8 * q, 0, ncols);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float v = acc[i][j][4 * q + e] + bv;
+          if (EPI == EPI_RESID) v += res[4 * q + e];
+          bstore1(v, cr, (int)vo[e]);
+        }
       }
     }
   }
+  AMK_STAMP(3);
 }
 
 // =============================================================================================================
 // NN: C[m, n] = sum_k A[m, k] W[k, n].  A (M, K) "R" image, W (K, N) "C" image.
 // Contraction segments: k in [0, split) reads (a, w), k in [split, K) reads (a2, w2) at k - split (split = 0: one).
 // SwiGLU backward: N = H, the tile is dG; c = (dA | dB) (M, 2H), ab = the forward's (a | b).
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nn_kernel(Params p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+template <int BK, int EPI>
+__global__ AMK_DENSE_BOUNDS(BK) void gemm_nn_kernel(Params p) {
+  using G = Geo<BK>;
+  constexpr int NP = G::NP, LSR = G::LSR;
+  __shared__ __attribute__((aligned(16))) float smem[2 * G::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
+  stagger(p, (BK == 16 ? 3 : 2) * 256);
+  __builtin_amdgcn_s_setprio(AMK_DENSE_EDGE_PRIO);
   const int u = xcd_remap(blockIdx.x, p.total);
   const int mt = u / p.ntn, nt = u - mt * p.ntn;
   const int64_t m0 = (int64_t)mt * 128;
@@ -306,19 +414,19 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(Params p) {
   const int K0 = p.split > 0 ? p.split : p.K, K1 = p.K - K0;
   const int nk0 = (K0 + BK - 1) / BK, nk1 = (K1 + BK - 1) / BK, nk = nk0 + nk1;
 
-  const int sr = tid >> 3, sc = (tid & 7) * 4;   // A pieces: rows sr + 32 j, 4 floats at column sc
-  const int cr = tid >> 5, cc = (tid & 31) * 4;  // W pieces: contraction rows cr + 8 j, 4 floats at column cc
+  const int sr = tid / G::TPR, sc = (tid % G::TPR) * 4;   // A pieces: rows sr + RPP j, 4 floats at column sc
+  const int cr = tid >> 5, cc = (tid & 31) * 4;           // W pieces: contraction rows cr + 8 j, 4 floats at column cc
   const bool col_ok = n0 + cc < p.N;
   // byte offsets of this thread's pieces inside the row panel of A / the slab of W, per contraction segment
-  unsigned aoff0[4], aoff1[4], woff0[4], woff1[4];
+  unsigned aoff0[NP], aoff1[NP], woff0[NP], woff1[NP];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    aoff0[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda + sc) * 4);
-    aoff1[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda2 + sc) * 4);
+  for (int j = 0; j < NP; ++j) {
+    aoff0[j] = (unsigned)(((int64_t)(sr + G::RPP * j) * p.lda + sc) * 4);
+    aoff1[j] = (unsigned)(((int64_t)(sr + G::RPP * j) * p.lda2 + sc) * 4);
     woff0[j] = col_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw + n0 + cc) * 4) : ROW_PAST;
     woff1[j] = col_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw2 + n0 + cc) * 4) : ROW_PAST;
   }
-  float4 stg[8];
+  float4 stg[2 * NP];
   // segment state of the tile being loaded (wave-uniform)
   auto seg_of = [&](int kt, int& s, int& k0) {
     const int t = kt < nk ? kt : nk - 1;
@@ -331,18 +439,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(Params p) {
     const float* wb_ = s ? p.w2 : p.w;
     const int64_t ldw = s ? p.ldw2 : p.ldw;
     const int Ks = s ? K1 : K0;
-    if (i < 4) {
+    if (i < NP) {
       const __amdgpu_buffer_rsrc_t ar = mkrsrc(ab_ + m0 * lda, ((int64_t)(rows - 1) * lda + Ks) * 4);
       const unsigned off = (k0 + sc < Ks) ? (s ? aoff1[i] : aoff0[i]) + (unsigned)(k0 * 4) : K_PAST;
       stg[i] = bload4(ar, (int)off);
     } else {
       const __amdgpu_buffer_rsrc_t wr = mkrsrc(wb_, ((int64_t)(Ks - 1) * ldw + p.N) * 4);
-      stg[i] = bload4(wr, (int)((s ? woff1[i - 4] : woff0[i - 4]) + (unsigned)(k0 * ldw * 4)));
+      stg[i] = bload4(wr, (int)((s ? woff1[i - NP] : woff0[i - NP]) + (unsigned)(k0 * ldw * 4)));
     }
   };
   auto lstore = [&](int i, float* stage) {
-    if (i < 4) st4(&stage[(sr + 32 * i) * LSR + sc], stg[i]);
-    else st4(&stage[BREG + (cr + 8 * (i - 4)) * LSC + cc], stg[i]);
+    if (i < NP) st4(&stage[(sr + G::RPP * i) * LSR + sc], stg[i]);
+    else st4(&stage[G::BREG + (cr + 8 * (i - NP)) * LSC + cc], stg[i]);
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -352,13 +460,12 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(Params p) {
   int s, k0;
   seg_of(0, s, k0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) gload_tile_piece(i, s, k0);
+  for (int i = 0; i < 2 * NP; ++i) gload_tile_piece(i, s, k0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) lstore(i, smem);
+  for (int i = 0; i < 2 * NP; ++i) lstore(i, smem);
   seg_of(1, s, k0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) gload_tile_piece(i, s, k0);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int i = 0; i < 2 * NP; ++i) gload_tile_piece(i, s, k0);
   __syncthreads();
   int s2 = 0, k2 = 0;
   auto mv = [&](int i, float* nxt, int kt) {
@@ -366,49 +473,50 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(Params p) {
     lstore(i, nxt);
     gload_tile_piece(i, s2, k2);
   };
-  const int a_rd = (64 * wm + ln) * LSR + 16 * hf;
-  const int b_rd = (16 * hf) * LSC + 64 * wn + ln;
-  step_loop<false, true>(acc, smem, nk, a_rd, 32 * LSR, b_rd, 32, mv);
+  const int a_rd = (64 * wm + ln) * LSR + (BK / 2) * hf;
+  const int b_rd = ((BK / 2) * hf) * LSC + 64 * wn + ln;
+  __builtin_amdgcn_s_setprio(0);
+  step_loop<BK, false, true>(acc, smem, nk, a_rd, 32 * LSR, b_rd, 32, mv);
+  __builtin_amdgcn_s_setprio(AMK_DENSE_EDGE_PRIO);
 
-  const int row0 = 64 * wm + 4 * hf;
-  if (EPI == EPI_SWIGLU_BWD) {
-    const __amdgpu_buffer_rsrc_t abr = mkrsrc(p.ab + m0 * p.ldab, ((int64_t)(rows - 1) * p.ldab + 2 * p.H) * 4);
-    const __amdgpu_buffer_rsrc_t cr_ = mkrsrc(p.c + m0 * p.ldc, ((int64_t)(rows - 1) * p.ldc + 2 * p.H) * 4);
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + 64 * wn + 32 * j + ln;
-      const unsigned cn = n < p.H ? (unsigned)n * 4u : K_PAST;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        float av[16], bv[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
-          av[r] = bload1(abr, (int)((unsigned)(row * p.ldab * 4) + cn));
-          bv[r] = bload1(abr, (int)((unsigned)(row * p.ldab * 4) + cn + (unsigned)p.H * 4u));
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
-          const float g = acc[i][j][r], sg = sigmoidf_(av[r]);
-          bstore1(g * bv[r] * (sg * (1.f + av[r] * (1.f - sg))), cr_, (int)((unsigned)(row * p.ldc * 4) + cn));
-          bstore1(g * (av[r] * sg), cr_, (int)((unsigned)(row * p.ldc * 4) + cn + (unsigned)p.H * 4u));
-        }
-      }
-    }
-    return;
-  }
-  const __amdgpu_buffer_rsrc_t cr_ = mkrsrc(p.c + m0 * p.ldc, ((int64_t)(rows - 1) * p.ldc + p.N) * 4);
+  const float* cbase = p.c + m0 * p.ldc;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int n = n0 + 64 * wn + 32 * j + ln;
     const unsigned cn = n < p.N ? (unsigned)n * 4u : K_PAST;
+    unsigned vo[4], va[4];
+    lane_offsets(vo, hf, p.ldc, cn);
+    if (EPI == EPI_SWIGLU_BWD) lane_offsets(va, hf, p.ldab, cn);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if constexpr (EPI == EPI_SWIGLU_BWD) {  // N = H: the tile is dGate; (a | b) in, (dA | dB) out
+        const float* abbase = p.ab + m0 * p.ldab;
+        float av[16], bv[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
-        bstore1(acc[i][j][r], cr_, (int)((unsigned)(row * p.ldc * 4) + cn));
+        for (int q = 0; q < 4; ++q) {
+          const int rg0 = 64 * wm + 32 * i + 8 * q;
+          const __amdgpu_buffer_rsrc_t ar = group_rsrc(abbase, p.ldab, rows, rg0, 0, p.H), br = group_rsrc(abbase, p.ldab, rows, rg0, p.H, p.H);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { av[4 * q + e] = bload1(ar, (int)va[e]); bv[4 * q + e] = bload1(br, (int)va[e]); }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int rg0 = 64 * wm + 32 * i + 8 * q;
+          const __amdgpu_buffer_rsrc_t dar = group_rsrc(cbase, p.ldc, rows, rg0, 0, p.H), dbr = group_rsrc(cbase, p.ldc, rows, rg0, p.H, p.H);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g = acc[i][j][4 * q + e], a_ = av[4 * q + e], sg = sigmoidf_(a_);
+            bstore1(g * bv[4 * q + e] * (sg * (1.f + a_ * (1.f - sg))), dar, (int)vo[e]);
+            bstore1(g * (a_ * sg), dbr, (int)vo[e]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const __amdgpu_buffer_rsrc_t cr_ = group_rsrc(cbase, p.ldc, rows, 64 * wm + 32 * i + 8 * q, 0, p.N);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) bstore1(acc[i][j][4 * q + e], cr_, (int)vo[e]);
+        }
       }
     }
   }
@@ -418,14 +526,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nn_kernel(Params p) {
 // TN: C[n, k] = sum_m Y[m, n] X'[m, k]; Y (M, N) and X (M, K) both "C" images (the contraction is the row index).
 // Row segments of the output: n in [0, split) reads Y = a (lda) and writes c; n in [split, N) reads a2 (lda2) and
 // writes c2 (dq | dkv).  X = w (ldw), optionally LayerNorm(X) (mean / rstd per row m, gamma / beta per column k).
-// The M rows are cut into nchunk chunks of steps_per_chunk 32-row steps; with nchunk > 1 every workgroup writes its
+// The M rows are cut into nchunk chunks of steps_per_chunk BK-row steps; with nchunk > 1 every workgroup writes its
 // partial tile to ws[chunk] (chunks, N, K) and tn_reduce_kernel sums the chunks in order.  dbias (column sums of
 // Y) is accumulated by the workgroups of the first k tile from the pieces they stage.
-template <bool LNX>
-__global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Params p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+template <int BK, bool LNX>
+__global__ AMK_DENSE_BOUNDS(BK) void gemm_tn_kernel(Params p) {
+  using G = Geo<BK>;
+  constexpr int NP = G::NP;
+  __shared__ __attribute__((aligned(16))) float smem[2 * G::STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
+  stagger(p, (BK == 16 ? 3 : 2) * 256);
+  __builtin_amdgcn_s_setprio(AMK_DENSE_EDGE_PRIO);
   // unit = (tile, chunk), chunks of one tile adjacent; tiles [n tile][k tile]
   const int u = xcd_remap(blockIdx.x, p.total);
   const int tile = u / p.nchunk, chunk = u - tile * p.nchunk;
@@ -450,42 +562,42 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Params p) {
   const __amdgpu_buffer_rsrc_t m_rsrc = mkrsrc(LNX ? p.ln_mean + mbeg : p.a, LNX ? (int64_t)mrows * 4 : 0);
   const __amdgpu_buffer_rsrc_t r_rsrc = mkrsrc(LNX ? p.ln_rstd + mbeg : p.a, LNX ? (int64_t)mrows * 4 : 0);
   const bool ycol_ok = n0 + cc < nrows, xcol_ok = k0t + cc < p.K;
-  unsigned goff[8];
+  unsigned goff[2 * NP];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < NP; ++j) {
     goff[j] = ycol_ok ? (unsigned)(((int64_t)(cr + 8 * j) * ldy + n0 + cc) * 4) : ROW_PAST;
-    goff[4 + j] = xcol_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw + k0t + cc) * 4) : ROW_PAST;
+    goff[NP + j] = xcol_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw + k0t + cc) * 4) : ROW_PAST;
   }
   const unsigned ystep = (unsigned)(BK * ldy * 4), xstep = (unsigned)(BK * p.ldw * 4);
   float4 gam = make_float4(0.f, 0.f, 0.f, 0.f), bet = gam;
   if (LNX && xcol_ok) { gam = ld4(p.ln_gamma + k0t + cc); bet = ld4(p.ln_beta + k0t + cc); }
-  float4 stg[8];
-  float mu[4], rs[4];
+  float4 stg[2 * NP];
+  float mu[NP], rs[NP];
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
   const bool do_bias = p.dbias != nullptr && tk == 0;
   auto gload = [&](int i, int kt) {  // (rows past the chunk: past the descriptor, zeros)
     const int t = kt < nk ? kt : nk - 1;
-    if (i < 4) stg[i] = bload4(y_rsrc, (int)(goff[i] + (unsigned)t * ystep));
+    if (i < NP) stg[i] = bload4(y_rsrc, (int)(goff[i] + (unsigned)t * ystep));
     else {
       stg[i] = bload4(x_rsrc, (int)(goff[i] + (unsigned)t * xstep));
       if (LNX) {
-        mu[i - 4] = bload1(m_rsrc, (t * BK + cr + 8 * (i - 4)) * 4);
-        rs[i - 4] = bload1(r_rsrc, (t * BK + cr + 8 * (i - 4)) * 4);
+        mu[i - NP] = bload1(m_rsrc, (t * BK + cr + 8 * (i - NP)) * 4);
+        rs[i - NP] = bload1(r_rsrc, (t * BK + cr + 8 * (i - NP)) * 4);
       }
     }
   };
   auto lstore = [&](int i, float* stage, bool count) {
     float4 v = stg[i];
-    if (i < 4) {
+    if (i < NP) {
       if (do_bias && count) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
       st4(&stage[(cr + 8 * i) * LSC + cc], v);
     } else {
       if (LNX) {
-        const float m_ = mu[i - 4], r_ = rs[i - 4];
+        const float m_ = mu[i - NP], r_ = rs[i - NP];
         v.x = fmaf((v.x - m_) * r_, gam.x, bet.x); v.y = fmaf((v.y - m_) * r_, gam.y, bet.y);
         v.z = fmaf((v.z - m_) * r_, gam.z, bet.z); v.w = fmaf((v.w - m_) * r_, gam.w, bet.w);
       }
-      st4(&stage[BREG + (cr + 8 * (i - 4)) * LSC + cc], v);
+      st4(&stage[G::BREG + (cr + 8 * (i - NP)) * LSC + cc], v);
     }
   };
   f32x16 acc[2][2];
@@ -494,20 +606,21 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Params p) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
 #pragma unroll
-  for (int i = 0; i < 8; ++i) gload(i, 0);
+  for (int i = 0; i < 2 * NP; ++i) gload(i, 0);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) lstore(i, smem, true);
+  for (int i = 0; i < 2 * NP; ++i) lstore(i, smem, true);
 #pragma unroll
-  for (int i = 0; i < 8; ++i) gload(i, 1);
-  __builtin_amdgcn_s_waitcnt(0x0F70);
+  for (int i = 0; i < 2 * NP; ++i) gload(i, 1);
   __syncthreads();
   auto mv = [&](int i, float* nxt, int kt) {
     lstore(i, nxt, kt + 1 < nk);  // (the re-read tile past the end is stored, never used, and not counted)
     gload(i, kt + 2);
   };
-  const int a_rd = (16 * hf) * LSC + 64 * wm + ln;
-  const int b_rd = (16 * hf) * LSC + 64 * wn + ln;
-  step_loop<true, true>(acc, smem, nk, a_rd, 32, b_rd, 32, mv);
+  const int a_rd = ((BK / 2) * hf) * LSC + 64 * wm + ln;
+  const int b_rd = ((BK / 2) * hf) * LSC + 64 * wn + ln;
+  __builtin_amdgcn_s_setprio(0);
+  step_loop<BK, true, true>(acc, smem, nk, a_rd, 32, b_rd, 32, mv);
+  __builtin_amdgcn_s_setprio(AMK_DENSE_EDGE_PRIO);
 
   // ---- epilogue: the partial tile
   float* Cb;
@@ -515,18 +628,20 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Params p) {
   if (p.nchunk > 1) { Cb = p.ws + ((int64_t)chunk * p.N + (seg ? p.split : 0)) * p.K; ldc = p.K; }
   else { Cb = seg ? p.c2 : p.c; ldc = seg ? p.ldc2 : p.ldc; }
   const int orow = nrows - n0 < 128 ? nrows - n0 : 128;  // valid rows of the tile
-  const __amdgpu_buffer_rsrc_t c_rsrc = mkrsrc(Cb + (int64_t)n0 * ldc, ((int64_t)(orow - 1) * ldc + p.K) * 4);
-  const int row0 = 64 * wm + 4 * hf;
+  const float* cbase = Cb + (int64_t)n0 * ldc;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int kcol = k0t + 64 * wn + 32 * j + ln;
     const unsigned cn = kcol < p.K ? (unsigned)kcol * 4u : K_PAST;
+    unsigned vo[4];
+    lane_offsets(vo, hf, ldc, cn);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + 32 * i + (r & 3) + 8 * (r >> 2);
-        bstore1(acc[i][j][r], c_rsrc, (int)((unsigned)(row * ldc * 4) + cn));
+      for (int q = 0; q < 4; ++q) {
+        const __amdgpu_buffer_rsrc_t cr_ = group_rsrc(cbase, ldc, orow, 64 * wm + 32 * i + 8 * q, 0, p.K);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) bstore1(acc[i][j][4 * q + e], cr_, (int)vo[e]);
       }
     }
   }
@@ -542,573 +657,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_kernel(Params p) {
       if (n < nrows) p.dbias[(int64_t)(p.nchunk > 1 ? chunk : 0) * p.N + (seg ? p.split : 0) + n] = s;
     }
   }
-}
-
-
-// =============================================================================================================
-// Persistent form of the three products.  A workgroup walks units u = blockIdx.x, + gridDim.x, ... (a unit = one
-// output tile, or for TN one (tile, chunk of rows)); the global loads run two steps ahead of the MFMAs ACROSS units,
-// so only the first unit of a workgroup pays the memory latency of its first tiles, and the barrier of a step sits
-// after its third MFMA group: the fragments of the next step's first group are read behind it, under the MFMAs of
-// the fourth group, and a step never starts by waiting for LDS.
-//   step s:  group 0..2: [read fragments of group g+1] [store pieces of step s+1 to the other stage, refill them
-//                         with step s+2] 16 MFMA
-//            barrier (LDS only: lgkmcnt(0), the loads stay in flight)
-//            group 3:    [read fragments of step s+1, group 0] 16 MFMA
-// Writes into a stage begin after the barrier of the step that last read it (all its fragment reads are issued
-// before that barrier); reads of a stage begin after the barrier that follows its last write.
-__device__ __forceinline__ void lds_barrier() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-  __builtin_amdgcn_s_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-
-// Epilogue addressing.  A lane's 16 values of a 32x32 accumulator are rows e + 8 q + 4 hf (e, q = 0..3) of one column:
-// per group of 8 rows (i, q) a descriptor of its own (scalar registers: base at the group's first row, records up to
-// the last VALID row of the group -- rows past the matrix are dropped by the range check) and four lane offsets
-// (rows 4 hf + e, the lane's column) shared by all groups: 4 vector registers per leading dimension instead of 32.
-__device__ __forceinline__ void lane_offsets(unsigned (&vo)[4], int hf, int64_t ld, unsigned colbytes) {
-#pragma unroll
-  for (int e = 0; e < 4; ++e) vo[e] = (unsigned)((4 * hf + e) * ld * 4) + colbytes;  // (colbytes may carry K_PAST)
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t group_rsrc(const float* base, int64_t ld, int rows, int rg0, int col0, int width) {
-  int n = rows - rg0;
-  n = n > 8 ? 8 : n;
-  return mkrsrc(base + (int64_t)rg0 * ld + col0, n > 0 ? ((int64_t)(n - 1) * ld + width) * 4 : 0);
-}
-
-template <bool ACT, bool BCT>
-__device__ __forceinline__ void read_frag(const float* st, int a_rd, int a_blk, int b_rd, int b_blk, int s4,
-                                          float (&fa)[2][4], float (&fb)[2][4]) {
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    if constexpr (!ACT) {
-      const float4 v = ld4(st + a_rd + i * a_blk + 4 * s4);
-      fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
-    } else {
-#pragma unroll
-      for (int x = 0; x < 4; ++x) fa[i][x] = st[a_rd + i * a_blk + (4 * s4 + x) * LSC];
-    }
-    if constexpr (!BCT) {
-      const float4 v = ld4(st + BREG + b_rd + i * b_blk + 4 * s4);
-      fb[i][0] = v.x; fb[i][1] = v.y; fb[i][2] = v.z; fb[i][3] = v.w;
-    } else {
-#pragma unroll
-      for (int x = 0; x < 4; ++x) fb[i][x] = st[BREG + b_rd + i * b_blk + (4 * s4 + x) * LSC];
-    }
-  }
-}
-
-__device__ __forceinline__ void mfma_group(f32x16 (&acc)[2][2], const float (&a)[2][4], const float (&b)[2][4]) {
-#pragma unroll
-  for (int x = 0; x < 4; ++x) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i][x], b[j][x], acc[i][j]);
-    }
-  }
-}
-
-// Unit interface:  int total;  int load_unit(int u) -> steps of unit u, and makes it the unit the loads address;
-//                  void gload(int i, int kt);  void lstore(int i, float* stage);  int steps(int u);
-//                  void epilogue(f32x16 (&acc)[2][2], int u);
-template <bool ACT, bool BCT, class Unit>
-__device__ __forceinline__ void persistent(Unit& U, float* smem, int a_rd, int a_blk, int b_rd, int b_blk) {
-  const int G = gridDim.x;
-  int cu = blockIdx.x;
-  if (cu >= U.total) return;
-  int lu = cu, lk = 0;
-  int lnk = U.load_unit(lu);
-  auto advance = [&]() {
-    if (++lk == lnk) {
-      lk = 0;
-      lu = lu + G < U.total ? lu + G : lu;  // past the end: the last unit again (loaded, never used)
-      lnk = U.load_unit(lu);
-    }
-  };
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) U.gload(i, lk);
-  advance();
-#pragma unroll
-  for (int i = 0; i < 8; ++i) U.lstore(i, smem);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) U.gload(i, lk);
-  advance();
-  lds_barrier();
-  float a[2][4], b[2][4];
-  read_frag<ACT, BCT>(smem, a_rd, a_blk, b_rd, b_blk, 0, a, b);
-  int ck = 0, cnk = U.steps(cu);
-  for (int s = 0;; ++s) {
-    const float* cur = smem + (s & 1) * STAGE;
-    float* nxt = smem + ((s + 1) & 1) * STAGE;
-    float an[2][4], bn[2][4];
-    U.stores_are_for_current_unit(ck + 1 < cnk);
-    auto mv = [&](int i) { U.lstore(i, nxt); U.gload(i, lk); };
-    auto take = [&]() {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int x = 0; x < 4; ++x) { a[i][x] = an[i][x]; b[i][x] = bn[i][x]; }
-    };
-    // group 0
-    read_frag<ACT, BCT>(cur, a_rd, a_blk, b_rd, b_blk, 1, an, bn);
-    mv(0); mv(1); mv(2);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(acc, a, b);
-    __builtin_amdgcn_sched_barrier(0);
-    take();
-    // group 1
-    read_frag<ACT, BCT>(cur, a_rd, a_blk, b_rd, b_blk, 2, an, bn);
-    mv(3); mv(4); mv(5);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(acc, a, b);
-    __builtin_amdgcn_sched_barrier(0);
-    take();
-    // group 2
-    read_frag<ACT, BCT>(cur, a_rd, a_blk, b_rd, b_blk, 3, an, bn);
-    mv(6); mv(7);
-    advance();
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(acc, a, b);
-    __builtin_amdgcn_sched_barrier(0);
-    take();
-    lds_barrier();
-    // group 3, with the first fragments of the next step read from the other stage
-    read_frag<ACT, BCT>(nxt, a_rd, a_blk, b_rd, b_blk, 0, an, bn);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(acc, a, b);
-    __builtin_amdgcn_sched_barrier(0);
-    take();
-    if (++ck == cnk) {
-      U.epilogue(acc, cu, smem + (s & 1) * STAGE);
-      cu += G;
-      if (cu >= U.total) break;
-      ck = 0;
-      cnk = U.steps(cu);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
-    }
-  }
-}
-
-// ---- NT ------------------------------------------------------------------------------------------------------
-template <int EPI, bool LNA>
-struct NtUnit {
-  static constexpr bool SW = EPI == EPI_SWIGLU;
-  const Params& p;
-  int total, tid, sr, sc, ln, hf, wm, wn, nk;
-  // load side
-  __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc, g_rsrc, be_rsrc, m_rsrc, r_rsrc;
-  unsigned goff[8];
-  float4 stg[8], gam, bet;
-  float mu[4], rs[4];
-  unsigned ka;
-  __device__ __forceinline__ NtUnit(const Params& p_) : p(p_) {
-    total = p.total;
-    tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ln = lane & 31; hf = lane >> 5; wm = wave >> 1; wn = wave & 1;
-    sr = tid >> 3; sc = (tid & 7) * 4;
-    nk = (p.K + BK - 1) / BK;
-    g_rsrc = mkrsrc(LNA ? p.ln_gamma : p.a, LNA ? (int64_t)p.K * 4 : 0);
-    be_rsrc = mkrsrc(LNA ? p.ln_beta : p.a, LNA ? (int64_t)p.K * 4 : 0);
-  }
-  // unit -> (row tile, column tile, column segment)
-  __device__ __forceinline__ void decode(int u, int64_t& m0, int& rows, int& n0, bool& seg, int& ncols) const {
-    const int v = xcd_remap(u, p.total);
-    const int mt = v / p.ntn, nt = v - mt * p.ntn;
-    m0 = (int64_t)mt * 128;
-    rows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
-    n0 = SW ? nt * 64 : nt * 128;
-    seg = !SW && p.split > 0 && n0 >= p.split;
-    ncols = SW ? p.H : (p.split > 0 ? (seg ? p.N - p.split : p.split) : p.N);
-    if (seg) n0 -= p.split;
-  }
-  __device__ __forceinline__ int steps(int) const { return nk; }
-  __device__ __forceinline__ int load_unit(int u) {
-    int64_t m0; int rows, n0, ncols; bool seg;
-    decode(u, m0, rows, n0, seg, ncols);
-    const float* Wb = seg ? p.w2 : p.w;
-    const int64_t ldw = seg ? p.ldw2 : p.ldw;
-    const int wrows = SW ? 2 * p.H : ncols;
-    a_rsrc = mkrsrc(p.a + m0 * p.lda, ((int64_t)(rows - 1) * p.lda + p.K) * 4);
-    w_rsrc = mkrsrc(Wb, ((int64_t)(wrows - 1) * ldw + p.K) * 4);
-    if (LNA) { m_rsrc = mkrsrc(p.ln_mean + m0, (int64_t)rows * 4); r_rsrc = mkrsrc(p.ln_rstd + m0, (int64_t)rows * 4); }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) goff[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda + sc) * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int rr = sr + 32 * j;
-      int wr; bool ok;
-      if (SW) { const int jj = n0 + (rr & 63); ok = jj < p.H; wr = (rr < 64 ? 0 : p.H) + jj; }
-      else { wr = n0 + rr; ok = wr < ncols; }
-      goff[4 + j] = ok ? (unsigned)(((int64_t)wr * ldw + sc) * 4) : ROW_PAST;
-    }
-    return nk;
-  }
-  __device__ __forceinline__ void gload(int i, int kt) {
-    if (i == 0) { const int k0 = kt * BK; ka = (k0 + sc < p.K) ? (unsigned)(k0 * 4) : K_PAST; }
-    if (i < 4) {
-      stg[i] = bload4(a_rsrc, (int)(goff[i] + ka));
-      if (LNA) { mu[i] = bload1(m_rsrc, (sr + 32 * i) * 4); rs[i] = bload1(r_rsrc, (sr + 32 * i) * 4); }
-      // gamma / beta of the tile's 4 columns (zeros past K: the K tail stays zero); reloaded once the A pieces of
-      // the previous tile are stored
-      if (LNA && i == 3) { gam = bload4(g_rsrc, (int)(ka + sc * 4)); bet = bload4(be_rsrc, (int)(ka + sc * 4)); }
-    } else stg[i] = bload4(w_rsrc, (int)(goff[i] + ka));
-  }
-  __device__ __forceinline__ void lstore(int i, float* stage) {
-    float4 v = stg[i];
-    if (LNA && i < 4) {
-      v.x = fmaf((v.x - mu[i]) * rs[i], gam.x, bet.x); v.y = fmaf((v.y - mu[i]) * rs[i], gam.y, bet.y);
-      v.z = fmaf((v.z - mu[i]) * rs[i], gam.z, bet.z); v.w = fmaf((v.w - mu[i]) * rs[i], gam.w, bet.w);
-    }
-    st4(&stage[(i < 4 ? 0 : BREG) + (sr + 32 * (i & 3)) * LSR + sc], v);
-  }
-  __device__ __forceinline__ void stores_are_for_current_unit(bool) {}
-  __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], int u, float*) {
-    int64_t m0; int rows, n0, ncols; bool seg;
-    decode(u, m0, rows, n0, seg, ncols);
-    const float* bias = seg ? p.bias2 : p.bias;
-    float* Cb = seg ? p.c2 : p.c;
-    const int64_t ldc = seg ? p.ldc2 : p.ldc;
-    if constexpr (SW) {
-      const int j = n0 + 32 * wn + ln;
-      const bool ok = j < p.H;
-      const float ba = (bias && ok) ? bias[j] : 0.f, bb = (bias && ok) ? bias[p.H + j] : 0.f;
-      const unsigned cg = ok ? (unsigned)j * 4u : K_PAST;
-      unsigned vg[4], vc[4];
-      lane_offsets(vg, hf, p.ldg, cg);
-      lane_offsets(vc, hf, ldc, cg);
-      const float* gbase = p.gate + m0 * p.ldg;
-      const float* abase = Cb ? Cb + m0 * ldc : p.gate;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rg0 = 64 * wm + 32 * i + 8 * q;
-          const __amdgpu_buffer_rsrc_t gr = group_rsrc(gbase, p.ldg, rows, rg0, 0, p.H);
-          const __amdgpu_buffer_rsrc_t ar = group_rsrc(abase, ldc, Cb ? rows : 0, rg0, 0, p.H);
-          const __amdgpu_buffer_rsrc_t br = group_rsrc(abase, ldc, Cb ? rows : 0, rg0, p.H, p.H);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float av = acc[i][0][4 * q + e] + ba, bv = acc[i][1][4 * q + e] + bb;
-            bstore1(av * sigmoidf_(av) * bv, gr, (int)vg[e]);
-            if (Cb) { bstore1(av, ar, (int)vc[e]); bstore1(bv, br, (int)vc[e]); }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-    } else {
-      const float* cbase = Cb + m0 * ldc;
-      const float* rbase = EPI == EPI_RESID ? p.resid + m0 * p.ldr : p.a;
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int n = n0 + 64 * wn + 32 * j + ln;
-        const bool ok = n < ncols;
-        const float bv = (bias && ok) ? bias[n] : 0.f;
-        const unsigned cn = ok ? (unsigned)n * 4u : K_PAST;
-        unsigned vo[4], vr[4];
-        lane_offsets(vo, hf, ldc, cn);
-        if (EPI == EPI_RESID) lane_offsets(vr, hf, p.ldr, cn);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            const int rg0 = 64 * wm + 32 * i + 8 * q;
-            const __amdgpu_buffer_rsrc_t cr = group_rsrc(cbase, ldc, rows, rg0, 0, ncols);
-            float res[4] = {0.f, 0.f, 0.f, 0.f};
-            if (EPI == EPI_RESID) {
-              const __amdgpu_buffer_rsrc_t rr = group_rsrc(rbase, p.ldr, rows, rg0, 0, ncols);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) res[e] = bload1(rr, (int)vr[e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bstore1(acc[i][j][4 * q + e] + bv + res[e], cr, (int)vo[e]);
-          }
-        }
-      }
-    }
-  }
-};
-
-template <int EPI, bool LNA>
-__global__ __launch_bounds__(256, 2) void gemm_nt_pkernel(Params p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-  NtUnit<EPI, LNA> U(p);
-  constexpr bool SW = EPI == EPI_SWIGLU;
-  const int a_rd = (64 * U.wm + U.ln) * LSR + 16 * U.hf;
-  const int b_rd = ((SW ? 32 : 64) * U.wn + U.ln) * LSR + 16 * U.hf;
-  persistent<false, false>(U, smem, a_rd, 32 * LSR, b_rd, (SW ? 64 : 32) * LSR);
-}
-
-// ---- NN ------------------------------------------------------------------------------------------------------
-template <int EPI>
-struct NnUnit {
-  const Params& p;
-  int total, tid, sr, sc, cr, cc, ln, hf, wm, wn, K0, K1, nk0, nk;
-  int64_t m0l;
-  int rowsl, n0l;
-  bool col_ok;
-  unsigned aoff0[4], aoff1[4], woff0[4], woff1[4];
-  float4 stg[8];
-  int sseg, sk0;
-  __device__ __forceinline__ NnUnit(const Params& p_) : p(p_) {
-    total = p.total;
-    tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ln = lane & 31; hf = lane >> 5; wm = wave >> 1; wn = wave & 1;
-    sr = tid >> 3; sc = (tid & 7) * 4; cr = tid >> 5; cc = (tid & 31) * 4;
-    K0 = p.split > 0 ? p.split : p.K; K1 = p.K - K0;
-    nk0 = (K0 + BK - 1) / BK;
-    nk = nk0 + (K1 + BK - 1) / BK;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      aoff0[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda + sc) * 4);
-      aoff1[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda2 + sc) * 4);
-    }
-  }
-  __device__ __forceinline__ void decode(int u, int64_t& m0, int& rows, int& n0) const {
-    const int v = xcd_remap(u, p.total);
-    const int mt = v / p.ntn, nt = v - mt * p.ntn;
-    m0 = (int64_t)mt * 128;
-    rows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
-    n0 = nt * 128;
-  }
-  __device__ __forceinline__ int steps(int) const { return nk; }
-  __device__ __forceinline__ int load_unit(int u) {
-    decode(u, m0l, rowsl, n0l);
-    col_ok = n0l + cc < p.N;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      woff0[j] = col_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw + n0l + cc) * 4) : ROW_PAST;
-      woff1[j] = col_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw2 + n0l + cc) * 4) : ROW_PAST;
-    }
-    return nk;
-  }
-  __device__ __forceinline__ void gload(int i, int kt) {
-    if (i == 0) { sseg = kt >= nk0; sk0 = (sseg ? kt - nk0 : kt) * BK; }
-    const int s = sseg, k0 = sk0;
-    const float* ab_ = s ? p.a2 : p.a;
-    const int64_t lda = s ? p.lda2 : p.lda;
-    const float* wb_ = s ? p.w2 : p.w;
-    const int64_t ldw = s ? p.ldw2 : p.ldw;
-    const int Ks = s ? K1 : K0;
-    if (i < 4) {
-      const __amdgpu_buffer_rsrc_t ar = mkrsrc(ab_ + m0l * lda, ((int64_t)(rowsl - 1) * lda + Ks) * 4);
-      const unsigned off = (k0 + sc < Ks) ? (s ? aoff1[i] : aoff0[i]) + (unsigned)(k0 * 4) : K_PAST;
-      stg[i] = bload4(ar, (int)off);
-    } else {
-      const __amdgpu_buffer_rsrc_t wr = mkrsrc(wb_, ((int64_t)(Ks - 1) * ldw + p.N) * 4);
-      stg[i] = bload4(wr, (int)((s ? woff1[i - 4] : woff0[i - 4]) + (unsigned)(k0 * ldw * 4)));
-    }
-  }
-  __device__ __forceinline__ void lstore(int i, float* stage) {
-    if (i < 4) st4(&stage[(sr + 32 * i) * LSR + sc], stg[i]);
-    else st4(&stage[BREG + (cr + 8 * (i - 4)) * LSC + cc], stg[i]);
-  }
-  __device__ __forceinline__ void stores_are_for_current_unit(bool) {}
-  __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], int u, float*) {
-    int64_t m0; int rows, n0;
-    decode(u, m0, rows, n0);
-    const float* cbase = p.c + m0 * p.ldc;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + 64 * wn + 32 * j + ln;
-      const unsigned cn = n < p.N ? (unsigned)n * 4u : K_PAST;
-      unsigned vo[4], va[4];
-      lane_offsets(vo, hf, p.ldc, cn);
-      if (EPI == EPI_SWIGLU_BWD) lane_offsets(va, hf, p.ldab, cn);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int rg0 = 64 * wm + 32 * i + 8 * q;
-          if constexpr (EPI == EPI_SWIGLU_BWD) {  // N = H: the tile is dGate; (a | b) in, (dA | dB) out
-            const float* abbase = p.ab + m0 * p.ldab;
-            const __amdgpu_buffer_rsrc_t ar = group_rsrc(abbase, p.ldab, rows, rg0, 0, p.H), br = group_rsrc(abbase, p.ldab, rows, rg0, p.H, p.H);
-            const __amdgpu_buffer_rsrc_t dar = group_rsrc(cbase, p.ldc, rows, rg0, 0, p.H), dbr = group_rsrc(cbase, p.ldc, rows, rg0, p.H, p.H);
-            float av[4], bv[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { av[e] = bload1(ar, (int)va[e]); bv[e] = bload1(br, (int)va[e]); }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float g = acc[i][j][4 * q + e], sg = sigmoidf_(av[e]);
-              bstore1(g * bv[e] * (sg * (1.f + av[e] * (1.f - sg))), dar, (int)vo[e]);
-              bstore1(g * (av[e] * sg), dbr, (int)vo[e]);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-          } else {
-            const __amdgpu_buffer_rsrc_t cr_ = group_rsrc(cbase, p.ldc, rows, rg0, 0, p.N);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) bstore1(acc[i][j][4 * q + e], cr_, (int)vo[e]);
-          }
-        }
-      }
-    }
-  }
-};
-
-template <int EPI>
-__global__ __launch_bounds__(256, 2) void gemm_nn_pkernel(Params p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-  NnUnit<EPI> U(p);
-  const int a_rd = (64 * U.wm + U.ln) * LSR + 16 * U.hf;
-  const int b_rd = (16 * U.hf) * LSC + 64 * U.wn + U.ln;
-  persistent<false, true>(U, smem, a_rd, 32 * LSR, b_rd, 32);
-}
-
-// ---- TN ------------------------------------------------------------------------------------------------------
-template <bool LNX>
-struct TnUnit {
-  const Params& p;
-  float* smem;
-  int total, tid, cr, cc, ln, hf, wm, wn;
-  __amdgpu_buffer_rsrc_t y_rsrc, x_rsrc, m_rsrc, r_rsrc;
-  unsigned goff[8], ystep, xstep;
-  int gcol;
-  float4 gam, bet, stg[8];
-  float4 bsum, bnext;  // column sums of the Y pieces stored for the unit being computed / for the unit after it
-  float mu[4], rs[4];
-  bool cur_unit;       // the pieces being stored belong to the unit being computed (set by the kernel's step hook)
-  __device__ __forceinline__ TnUnit(const Params& p_, float* smem_) : p(p_), smem(smem_) {
-    total = p.total;
-    tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    ln = lane & 31; hf = lane >> 5; wm = wave >> 1; wn = wave & 1;
-    cr = tid >> 5; cc = (tid & 31) * 4;
-    bsum = make_float4(0.f, 0.f, 0.f, 0.f);
-    bnext = bsum;
-    cur_unit = true;
-    xstep = (unsigned)(BK * p.ldw * 4);
-  }
-  // unit -> (n tile, k tile, chunk): chunks of one tile adjacent
-  __device__ __forceinline__ void decode(int u, int& n0, int& k0t, bool& seg, int& nrows, int& chunk, int64_t& mbeg, int& mrows) const {
-    const int v = xcd_remap(u, p.total);
-    const int tile = v / p.nchunk;
-    chunk = v - tile * p.nchunk;
-    const int tn = tile / p.ntn, tk = tile - tn * p.ntn;
-    n0 = tn * 128;
-    k0t = tk * 128;
-    seg = p.split > 0 && n0 >= p.split;
-    nrows = p.split > 0 ? (seg ? p.N - p.split : p.split) : p.N;
-    if (seg) n0 -= p.split;
-    mbeg = (int64_t)chunk * p.steps_per_chunk * BK;
-    int64_t mend = mbeg + (int64_t)p.steps_per_chunk * BK;
-    if (mend > p.M) mend = p.M;
-    mrows = (int)(mend - mbeg);
-  }
-  __device__ __forceinline__ int steps(int u) const {
-    int n0, k0t, nrows, chunk, mrows; bool seg; int64_t mbeg;
-    decode(u, n0, k0t, seg, nrows, chunk, mbeg, mrows);
-    return (mrows + BK - 1) / BK;
-  }
-  __device__ __forceinline__ int load_unit(int u) {
-    int n0, k0t, nrows, chunk, mrows; bool seg; int64_t mbeg;
-    decode(u, n0, k0t, seg, nrows, chunk, mbeg, mrows);
-    const float* Yb = seg ? p.a2 : p.a;
-    const int64_t ldy = seg ? p.lda2 : p.lda;
-    y_rsrc = mkrsrc(Yb + mbeg * ldy, ((int64_t)(mrows - 1) * ldy + nrows) * 4);
-    x_rsrc = mkrsrc(p.w + mbeg * p.ldw, ((int64_t)(mrows - 1) * p.ldw + p.K) * 4);
-    if (LNX) { m_rsrc = mkrsrc(p.ln_mean + mbeg, (int64_t)mrows * 4); r_rsrc = mkrsrc(p.ln_rstd + mbeg, (int64_t)mrows * 4); }
-    const bool ycol_ok = n0 + cc < nrows, xcol_ok = k0t + cc < p.K;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      goff[j] = ycol_ok ? (unsigned)(((int64_t)(cr + 8 * j) * ldy + n0 + cc) * 4) : ROW_PAST;
-      goff[4 + j] = xcol_ok ? (unsigned)(((int64_t)(cr + 8 * j) * p.ldw + k0t + cc) * 4) : ROW_PAST;
-    }
-    gcol = xcol_ok ? (k0t + cc) * 4 : (int)K_PAST;
-    ystep = (unsigned)(BK * ldy * 4);
-    return (mrows + BK - 1) / BK;
-  }
-  __device__ __forceinline__ void gload(int i, int kt) {  // (rows past the chunk: past the descriptor, zeros)
-    if (i < 4) stg[i] = bload4(y_rsrc, (int)(goff[i] + (unsigned)kt * ystep));
-    else {
-      stg[i] = bload4(x_rsrc, (int)(goff[i] + (unsigned)kt * xstep));
-      if (LNX) {
-        mu[i - 4] = bload1(m_rsrc, (kt * BK + cr + 8 * (i - 4)) * 4);
-        rs[i - 4] = bload1(r_rsrc, (kt * BK + cr + 8 * (i - 4)) * 4);
-        if (i == 7) {  // gamma / beta of this thread's 4 columns for the unit now loading (its predecessor's X pieces are stored)
-          const __amdgpu_buffer_rsrc_t gr = mkrsrc(p.ln_gamma, (int64_t)p.K * 4), br = mkrsrc(p.ln_beta, (int64_t)p.K * 4);
-          gam = bload4(gr, gcol);
-          bet = bload4(br, gcol);
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void lstore(int i, float* stage) {
-    float4 v = stg[i];
-    if (i < 4) {
-      if (cur_unit) { bsum.x += v.x; bsum.y += v.y; bsum.z += v.z; bsum.w += v.w; }
-      else { bnext.x += v.x; bnext.y += v.y; bnext.z += v.z; bnext.w += v.w; }
-      st4(&stage[(cr + 8 * i) * LSC + cc], v);
-    } else {
-      if (LNX) {
-        const float m_ = mu[i - 4], r_ = rs[i - 4];
-        v.x = fmaf((v.x - m_) * r_, gam.x, bet.x); v.y = fmaf((v.y - m_) * r_, gam.y, bet.y);
-        v.z = fmaf((v.z - m_) * r_, gam.z, bet.z); v.w = fmaf((v.w - m_) * r_, gam.w, bet.w);
-      }
-      st4(&stage[BREG + (cr + 8 * (i - 4)) * LSC + cc], v);
-    }
-  }
-  __device__ __forceinline__ void stores_are_for_current_unit(bool c) { cur_unit = c; }
-  // `red`: an LDS stage nobody reads or writes until the next step's stores (the one just computed from)
-  __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][2], int u, float* red) {
-    int n0, k0t, nrows, chunk, mrows; bool seg; int64_t mbeg;
-    decode(u, n0, k0t, seg, nrows, chunk, mbeg, mrows);
-    float* Cb;
-    int64_t ldc;
-    if (p.nchunk > 1) { Cb = p.ws + ((int64_t)chunk * p.N + (seg ? p.split : 0)) * p.K; ldc = p.K; }
-    else { Cb = seg ? p.c2 : p.c; ldc = seg ? p.ldc2 : p.ldc; }
-    const int orow = nrows - n0 < 128 ? nrows - n0 : 128;  // valid rows of the tile
-    const float* cbase = Cb + (int64_t)n0 * ldc;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int kcol = k0t + 64 * wn + 32 * j + ln;
-      const unsigned cn = kcol < p.K ? (unsigned)kcol * 4u : K_PAST;
-      unsigned vo[4];
-      lane_offsets(vo, hf, ldc, cn);
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const __amdgpu_buffer_rsrc_t cr_ = group_rsrc(cbase, ldc, orow, 64 * wm + 32 * i + 8 * q, 0, p.K);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) bstore1(acc[i][j][4 * q + e], cr_, (int)vo[e]);
-        }
-      }
-    }
-    if (p.dbias != nullptr && k0t == 0) {  // fold the eight row groups (cr) of each column quad (workgroup-uniform branch)
-      st4(&red[cr * 128 + cc], bsum);
-      lds_barrier();
-      if (tid < 128) {
-        float s_ = 0.f;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s_ += red[j * 128 + tid];
-        const int n = n0 + tid;
-        if (n < nrows) p.dbias[(int64_t)(p.nchunk > 1 ? chunk : 0) * p.N + (seg ? p.split : 0) + n] = s_;
-      }
-      lds_barrier();
-    }
-    bsum = bnext;
-    bnext = make_float4(0.f, 0.f, 0.f, 0.f);
-  }
-};
-
-template <bool LNX>
-__global__ __launch_bounds__(256, 2) void gemm_tn_pkernel(Params p) {
-  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
-  TnUnit<LNX> U(p, smem);
-  const int a_rd = (16 * U.hf) * LSC + 64 * U.wm + U.ln;
-  const int b_rd = (16 * U.hf) * LSC + 64 * U.wn + U.ln;
-  persistent<true, true>(U, smem, a_rd, 32, b_rd, 32);
 }
 
 // C = sum over chunks of ws (in chunk order).  Elements [0, split * K) go to c (rows of ldc), the rest to c2.
@@ -1176,29 +724,34 @@ using namespace amk_dense;
 
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// workgroups the chip holds at once: two per CU (LDS: 2 x 72 KiB of the 160 KiB)
-static int wg_slots() {
-  static int slots = 0;
-  if (slots == 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    slots = 2 * cus;
+// Step depth of the tile loop: 16 (40 KiB of LDS, three workgroups per CU) or 32 (72 KiB, two per CU).
+// AMK_DENSE_BK overrides the default (A/B switch of tools/kbench_dense.py).
+static int dense_bk() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("AMK_DENSE_BK");
+    v = (e && atoi(e) == 32) ? 32 : ((e && atoi(e) == 16) ? 16 : AMK_DENSE_DEFAULT_BK);
   }
-  return slots;
+  return v;
 }
-// AMK_DENSE_ONE_TILE=1: one workgroup per tile (the round-3 first cut) instead of the persistent walk -- A/B switch
-static bool one_tile() {
-  static int v = -1;
-  if (v < 0) { const char* e = getenv("AMK_DENSE_ONE_TILE"); v = (e && e[0] == '1') ? 1 : 0; }
-  return v == 1;
+// workgroups the chip holds at once
+static int wg_slots() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  return (dense_bk() == 16 ? 3 : 2) * cus;
 }
 
 static int tn_chunks(const amk_gemm_desc* d, int* steps_per_chunk) {
+  const int bk = dense_bk();
   const int tiles = ((d->n + 127) / 128) * ((d->k + 127) / 128);
-  const int64_t steps = (d->m + BK - 1) / BK;
-  int64_t chunks = wg_slots() / tiles;  // workgroup slots of the chip (two per CU) over the tiles
+  const int64_t steps = (d->m + bk - 1) / bk;
+  const int64_t min_steps = 256 / bk;  // at least 256 rows per chunk
+  int64_t chunks = wg_slots() / tiles;  // workgroup slots of the chip over the tiles
   if (chunks < 1) chunks = 1;
-  if (chunks > steps / 8) chunks = steps / 8 > 0 ? steps / 8 : 1;  // at least 8 steps per chunk
+  if (chunks > steps / min_steps) chunks = steps / min_steps > 0 ? steps / min_steps : 1;
   int64_t spc = (steps + chunks - 1) / chunks;
   chunks = (steps + spc - 1) / spc;
   *steps_per_chunk = (int)spc;
@@ -1245,6 +798,16 @@ extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_
   p.lda = d->lda; p.lda2 = d->lda2; p.ldw = d->ldw; p.ldw2 = d->ldw2; p.ldc = d->ldc; p.ldc2 = d->ldc2;
   p.ldr = d->ldr; p.ldab = d->ldab; p.ldg = d->ldg;
   p.M = d->m; p.N = d->n; p.K = d->k; p.split = d->split; p.H = d->n;
+  {
+    static int mode = -1, sleeps = 0;
+    if (mode < 0) {
+      const char* e = getenv("AMK_DENSE_STAGGER");   // "mode,sleeps"
+      mode = e ? atoi(e) : 0;
+      const char* c = e ? strchr(e, ',') : nullptr;
+      sleeps = c ? atoi(c + 1) : 2;
+    }
+    p.stagger_mode = mode; p.stagger_sleeps = sleeps;
+  }
   const bool ln = d->ln_mean != nullptr;
   if (ln) AMK_CHECK_ARG(d->ln_rstd && d->ln_gamma && d->ln_beta, "amk_gemm_f32: LayerNorm operand needs mean, rstd, gamma and beta");
   if (two) {
@@ -1262,12 +825,15 @@ extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_
     if (sw) AMK_CHECK_ARG(d->gate && d->ldg % 4 == 0, "amk_gemm_f32: SwiGLU epilogue needs the gate output");
     if (d->epilogue == AMK_EPI_RESID) AMK_CHECK_ARG(d->resid && !two && d->ldr % 4 == 0, "amk_gemm_f32: residual epilogue needs resid (one column segment)");
     p.ntn = sw ? (d->n + 63) / 64 : (two ? d->split / 128 + (d->n - d->split + 127) / 128 : (d->n + 127) / 128);
+#ifdef AMK_DENSE_STAMPS
+    p.ws = static_cast<float*>(workspace);  // diagnostic build: per-workgroup time stamps
+#endif
     const int64_t total = mt * p.ntn;
     AMK_CHECK_SUPPORTED(total < (int64_t)1 << 31, "amk_gemm_f32: grid too large");
     p.total = (int)total;
-    const bool pers = !one_tile();
-    const dim3 grid((unsigned)(pers && total > wg_slots() ? wg_slots() : total)), blk(256);
-#define AMK_NT(E, L) do { if (pers) hipLaunchKernelGGL((gemm_nt_pkernel<E, L>), grid, blk, 0, st, p); else hipLaunchKernelGGL((gemm_nt_kernel<E, L>), grid, blk, 0, st, p); } while (0)
+    const dim3 grid((unsigned)total), blk(256);
+    const bool b16 = dense_bk() == 16;
+#define AMK_NT(E, L) do { if (b16) hipLaunchKernelGGL((gemm_nt_kernel<16, E, L>), grid, blk, 0, st, p); else hipLaunchKernelGGL((gemm_nt_kernel<32, E, L>), grid, blk, 0, st, p); } while (0)
     if (sw) { if (ln) AMK_NT(EPI_SWIGLU, true); else AMK_NT(EPI_SWIGLU, false); }
     else if (d->epilogue == AMK_EPI_RESID) { if (ln) AMK_NT(EPI_RESID, true); else AMK_NT(EPI_RESID, false); }
     else if (d->epilogue == AMK_EPI_BIAS) { if (ln) AMK_NT(EPI_BIAS, true); else AMK_NT(EPI_BIAS, false); }
@@ -1289,15 +855,10 @@ extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_
     const int64_t total = mt * p.ntn;
     AMK_CHECK_SUPPORTED(total < (int64_t)1 << 31, "amk_gemm_f32: grid too large");
     p.total = (int)total;
-    const bool pers = !one_tile();
-    const dim3 grid((unsigned)(pers && total > wg_slots() ? wg_slots() : total));
-    if (pers) {
-      if (swb) hipLaunchKernelGGL((gemm_nn_pkernel<EPI_SWIGLU_BWD>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_nn_pkernel<EPI_BIAS>), grid, dim3(256), 0, st, p);
-    } else {
-      if (swb) hipLaunchKernelGGL((gemm_nn_kernel<EPI_SWIGLU_BWD>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_nn_kernel<EPI_BIAS>), grid, dim3(256), 0, st, p);
-    }
+    const dim3 grid((unsigned)total);
+    const bool b16 = dense_bk() == 16;
+    if (swb) { if (b16) hipLaunchKernelGGL((gemm_nn_kernel<16, EPI_SWIGLU_BWD>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((gemm_nn_kernel<32, EPI_SWIGLU_BWD>), grid, dim3(256), 0, st, p); }
+    else { if (b16) hipLaunchKernelGGL((gemm_nn_kernel<16, EPI_BIAS>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((gemm_nn_kernel<32, EPI_BIAS>), grid, dim3(256), 0, st, p); }
     AMK_CHECK_LAUNCH("amk_gemm_f32(NN)");
     return AMK_OK;
   }
@@ -1306,7 +867,7 @@ extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_
   AMK_CHECK_SUPPORTED(d->n % 4 == 0 && (!two || (d->n - d->split) % 4 == 0), "amk_gemm_f32(TN): N must be a multiple of 4");
   int spc;
   const int chunks = tn_chunks(d, &spc);
-  AMK_CHECK_SUPPORTED((int64_t)spc * BK * d->lda * 4 < lim && (int64_t)spc * BK * d->ldw * 4 < lim && (!two || (int64_t)spc * BK * d->lda2 * 4 < lim),
+  AMK_CHECK_SUPPORTED((int64_t)spc * 32 * d->lda * 4 < lim && (int64_t)spc * 32 * d->ldw * 4 < lim && (!two || (int64_t)spc * 32 * d->lda2 * 4 < lim),
                       "amk_gemm_f32(TN): chunk panel beyond 1 GiB");
   AMK_CHECK_SUPPORTED((int64_t)d->n * d->k * 4 < lim, "amk_gemm_f32(TN): output beyond 1 GiB");
   if (chunks > 1) {
@@ -1323,15 +884,10 @@ extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_
   if (two) AMK_CHECK_ARG(d->split % 128 == 0, "amk_gemm_f32(TN): split must be a multiple of 128");
   p.total = (int)total;
   {
-    const bool pers = !one_tile();
-    const dim3 grid((unsigned)(pers && total > wg_slots() ? wg_slots() : total));
-    if (pers) {
-      if (ln) hipLaunchKernelGGL((gemm_tn_pkernel<true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_tn_pkernel<false>), grid, dim3(256), 0, st, p);
-    } else {
-      if (ln) hipLaunchKernelGGL((gemm_tn_kernel<true>), grid, dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((gemm_tn_kernel<false>), grid, dim3(256), 0, st, p);
-    }
+    const dim3 grid((unsigned)total);
+    const bool b16 = dense_bk() == 16;
+    if (ln) { if (b16) hipLaunchKernelGGL((gemm_tn_kernel<16, true>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((gemm_tn_kernel<32, true>), grid, dim3(256), 0, st, p); }
+    else { if (b16) hipLaunchKernelGGL((gemm_tn_kernel<16, false>), grid, dim3(256), 0, st, p); else hipLaunchKernelGGL((gemm_tn_kernel<32, false>), grid, dim3(256), 0, st, p); }
   }
   AMK_CHECK_LAUNCH("amk_gemm_f32(TN)");
   if (chunks > 1) {
@@ -1341,4 +897,13 @@ extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_
     AMK_CHECK_LAUNCH("amk_gemm_f32(TN reduce)");
   }
   return AMK_OK;
+}
+
+// diagnostic (not part of the ABI): resident workgroups per CU the runtime computes for the NT kernel
+extern "C" int amk_debug_dense_occupancy(int bk) {
+  int n = -1;
+  hipError_t e;
+  if (bk == 16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<16, EPI_BIAS, false>, 256, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, gemm_nt_kernel<32, EPI_BIAS, false>, 256, 0);
+  return e == hipSuccess ? n : -(int)e;
 }
