@@ -39,8 +39,12 @@ class SoftmaxAttention(nn.Module):
 
     def forward(self, x, context=None, causal_mask=None, context_mask=None):
         src = x if context is None else context
-        q = self._drop(self.q(x))        # (B, I, h*d), consumed in place by the kernel
-        kv = self._drop(self.kv(src))    # (B, J, 2*h*d): '(kv h d)' columns
+        if context is None and x.is_cuda:
+            q, kv = ops.linear2(x, self.q[0].weight, self.kv[0].weight)  # self-attention: both projections in one launch
+            q, kv = self._drop(q), self._drop(kv)
+        else:
+            q = self._drop(self.q(x))        # (B, I, h*d), consumed in place by the kernel
+            kv = self._drop(self.kv(src))    # (B, J, 2*h*d): '(kv h d)' columns
         o = ops.attention_fused_kv(
             q, kv, self.num_heads, self.dim_head, self.scale,
             key_mask=context_mask, causal_mask=causal_mask,

@@ -32,11 +32,11 @@ class SwiGLU(nn.Module):
         self.w3 = Linear(hidden_features, out_features, bias=bias)
 
     def forward(self, x):
-        ab = self.w12(x)  # (..., 2*hidden) = (a | b)
-        if ab.shape[-1] % 8 == 0:
-            return self.w3(ops.swiglu(ab))            # fused gate kernel (amk_swiglu_fwd / _bwd)
-        a, b = ab.chunk(2, dim=-1)                      # widths the kernel does not take (hidden % 4 != 0)
-        return self.w3(F.silu(a) * b)
+        if not x.is_cuda:
+            a, b = self.w12(x).chunk(2, dim=-1)
+            return self.w3(F.silu(a) * b)
+        # the gate in the w12 GEMM's epilogue, its derivative in the w3 input gradient's (amk_gemm_f32)
+        return ops.swiglu_ffn(x, self.w12.weight, self.w12.bias, self.w3.weight, self.w3.bias)
 
 
 class FeedForward(SwiGLU):

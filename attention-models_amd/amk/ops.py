@@ -896,11 +896,146 @@ class _LinearX6(torch.autograd.Function):
         return dx, dw, db
 
 
+# Dense GEMMs of the nn.Linear layers, default path: csrc/gemm_f32.hip (amk_gemm_f32) -- the forward with the bias in
+# its epilogue, the weight gradient with the bias gradient (column sums of dY) inside the same product, q and kv
+# projections as one launch, the SwiGLU gate of the FFN in the w12 GEMM's epilogue and its derivative in the epilogue
+# of the w3 input gradient.  DENSE_MODE (AMK_DENSE): "amk" = every product on amk_gemm_f32; "auto" (default) = the
+# plain input gradient dY W stays with the vendor library where that is the faster kernel (measured,
+# tools/kbench_dense.py: 0.88-0.96x), everything else on amk_gemm_f32; "lib" = the round-2 path (library GEMMs +
+# amk_colsum / amk_swiglu launches).
+DENSE_MODE = os.environ.get("AMK_DENSE", "auto")
+
+
+def _dense_ok(x, *weights):
+    if DENSE_MODE == "lib" or torch.is_autocast_enabled() or not x.is_cuda or x.dtype != torch.float32 or x.numel() == 0:
+        return False
+    if x.shape[-1] % 4 or x.shape[-1] < 128:
+        return False
+    return all(w.dtype == torch.float32 and w.shape[0] % 4 == 0 and w.shape[0] >= 128 and w.is_contiguous() for w in weights)
+
+
+def _nn_plain(dy2, weight):
+    """dY W: the one product the library still wins on the step's shapes."""
+    from . import dense
+
+    if DENSE_MODE == "amk":
+        return dense.gemm_nn(dy2, weight)
+    return dy2.mm(weight)
+
+
+class _DenseLinear(torch.autograd.Function):
+    """F.linear on amk_gemm_f32: forward NT (+ bias), dX = dY W, dW = dY^T X with db = colsum(dY) in the same launch."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        from . import dense
+
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, weight)
+        ctx.x_shape = x.shape
+        ctx.has_bias = bias is not None
+        return dense.gemm_nt(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import dense
+
+        x2, weight = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _nn_plain(dy2, weight).view(ctx.x_shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            dw, _, db = dense.gemm_tn(dy2, x2, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+        return dx, dw, db
+
+
+class _DenseLinear2(torch.autograd.Function):
+    """Two bias-free projections of the same input (q and kv of SoftmaxAttention) as one launch each way:
+    (x Wa^T, x Wb^T); dX = dA Wa + dB Wb as one contraction in two segments; (dWa, dWb) from one launch."""
+
+    @staticmethod
+    def forward(ctx, x, wa, wb):
+        from . import dense
+
+        x2 = x.reshape(-1, x.shape[-1])
+        ctx.save_for_backward(x2, wa, wb)
+        ctx.x_shape = x.shape
+        a, b = dense.gemm_nt(x2, wa, None, w2=wb)
+        return a.view(*x.shape[:-1], wa.shape[0]), b.view(*x.shape[:-1], wb.shape[0])
+
+    @staticmethod
+    def backward(ctx, da, db_):
+        from . import dense
+
+        x2, wa, wb = ctx.saved_tensors
+        da2 = da.reshape(-1, da.shape[-1])
+        db2 = db_.reshape(-1, db_.shape[-1])
+        dx = dense.gemm_nn(da2, wa, a2=db2, w2=wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dwa = dwb = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dwa, dwb, _ = dense.gemm_tn(da2, x2, y2=db2)
+        return dx, dwa, dwb
+
+
+class _SwiGLUFFN(torch.autograd.Function):
+    """w3(silu(a) * b) with (a | b) = w12(x) (models/vitvqgan.py:20-34 as built, see amk/models/vitvqgan.py): the gate in
+    the epilogue of the w12 product ((a | b) is written only when a backward will read it), its derivative in the epilogue
+    of dGate = dOut W3, both bias gradients inside the weight-gradient products: six launches forward + backward where
+    the separate form took eighteen."""
+
+    @staticmethod
+    def forward(ctx, x, w12, b12, w3, b3):
+        from . import dense
+
+        x2 = x.reshape(-1, x.shape[-1])
+        need = any(ctx.needs_input_grad)
+        gate, ab = dense.gemm_nt_swiglu(x2, w12, b12, keep_ab=need)
+        out = dense.gemm_nt(gate, w3, b3)
+        if need:
+            ctx.save_for_backward(x2, w12, w3, ab, gate)
+        ctx.x_shape = x.shape
+        ctx.has_bias = (b12 is not None, b3 is not None)
+        return out.view(*x.shape[:-1], w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        from . import dense
+
+        x2, w12, w3, ab, gate = ctx.saved_tensors
+        d2 = dout.reshape(-1, dout.shape[-1])
+        d_ab = dense.gemm_nn(d2, w3, swiglu_ab=ab)
+        dw3, _, db3 = dense.gemm_tn(d2, gate, want_bias=ctx.has_bias[1])
+        dx = _nn_plain(d_ab, w12).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
+        dw12, _, db12 = dense.gemm_tn(d_ab, x2, want_bias=ctx.has_bias[0])
+        return dx, dw12, db12, dw3, db3
+
+
 def linear(x, weight, bias=None):
     if torch.is_autocast_enabled():  # mixed precision: the library GEMM in the autocast dtype, bias gradient by autograd
         return torch.nn.functional.linear(x, weight, bias)
     if GEMM_MODE == "bf16x6" and _x6_ok(x, weight):
         return _LinearX6.apply(x, weight, bias)
+    if _dense_ok(x, weight):
+        return _DenseLinear.apply(x, weight, bias)
     if bias is None:
         return torch.nn.functional.linear(x, weight)
     return _BiasLinear.apply(x, weight, bias)
+
+
+def linear2(x, wa, wb):
+    """(F.linear(x, wa), F.linear(x, wb)) -- one launch when the shapes allow (wa.shape[0] a multiple of 128)."""
+    if GEMM_MODE != "bf16x6" and _dense_ok(x, wa, wb) and wa.shape[0] % 128 == 0:
+        return _DenseLinear2.apply(x, wa, wb)
+    return linear(x, wa), linear(x, wb)
+
+
+def swiglu_ffn(x, w12, b12, w3, b3):
+    """w3(silu(a) * b), (a | b) = w12(x): fused (see _SwiGLUFFN) when the shapes allow, else the separate launches."""
+    if GEMM_MODE != "bf16x6" and _dense_ok(x, w12) and w3.shape[1] % 4 == 0 and w3.shape[0] % 4 == 0 and w3.is_contiguous():
+        return _SwiGLUFFN.apply(x, w12, b12, w3, b3)
+    ab = linear(x, w12, b12)
+    if ab.shape[-1] % 8 == 0:
+        return linear(swiglu(ab), w3, b3)
+    a, b = ab.chunk(2, dim=-1)
+    return linear(torch.nn.functional.silu(a) * b, w3, b3)

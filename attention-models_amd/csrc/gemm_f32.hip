@@ -26,6 +26,7 @@
 #include "amk_common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 #ifndef AMK_DENSE_DEFAULT_BK
 #define AMK_DENSE_DEFAULT_BK 32
@@ -71,6 +72,13 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t mkrsrc(const void* base, int64
   return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(bytes < 0 ? 0 : (bytes > 0x3FFFFFFF ? 0x3FFFFFFF : bytes)), 0x00020000);
 }
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// barrier that orders LDS only: the global loads in flight stay in flight (__syncthreads() would drain outstanding stores)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 
 enum { EPI_BIAS = 0, EPI_RESID = 1, EPI_SWIGLU = 2, EPI_SWIGLU_BWD = 3 };
 
@@ -391,6 +399,295 @@ __global__ AMK_DENSE_BOUNDS(BK) void gemm_nt_kernel(Params p) {
     }
   }
   AMK_STAMP(3);
+}
+
+// =============================================================================================================
+// NT, persistent form (K >= 4 steps).  Time stamps of the kernel above (tools/scratch/stamps.py) show where a 128 x
+// 128 x 256 tile loses a fifth of its time: all workgroups of a launch move in step, so every CU loads its first tiles
+// (2 us) and stores its results (4-5 us: 512 workgroups x 64 KiB hit HBM together) with nobody's MFMAs in flight,
+// and offsetting the two workgroups of a CU does not help -- a wave storing its results next to a partner in its tile
+// loop crawls (13 us).  Here a workgroup walks tiles u = blockIdx.x, + gridDim.x, ..., its global loads run two steps
+// ahead ACROSS tiles, and the results of tile n leave DURING the first four steps of tile n+1: at the end of a tile
+// the accumulators move to a second register set (64 v_mov), and each of the next 16 MFMA groups carries one
+// 8-row group of them -- bias, residual (loaded two groups ahead), SwiGLU gate, four to twelve buffer stores.  The
+// instruction stream of a wave is then the same all the way: 16 MFMA, a few loads / stores / LDS moves, 16 MFMA...
+template <int EPI, bool LNA>
+struct NtWalk {
+  static constexpr int BK = 32;
+  using G = Geo<32>;
+  static constexpr int LSR = G::LSR;
+  static constexpr bool SW = EPI == EPI_SWIGLU;
+  const Params& p;
+  int tid, sr, sc, ln, hf, wm, wn, nk;
+  // ---- load side (the tile whose operands are being fetched)
+  __amdgpu_buffer_rsrc_t a_rsrc, w_rsrc, g_rsrc, be_rsrc, m_rsrc, r_rsrc;
+  unsigned goff[8], ka;
+  float4 stg[8], gam, bet;
+  float mu[4], rs[4];
+  // ---- drain side (the tile whose results sit in accp)
+  f32x16 accp[2][2];
+  const float *cbase_d, *rbase_d, *gbase_d;
+  int64_t ldc_d;
+  int rows_d, ncols_d;
+  bool keep_ab_d;
+  unsigned vo[4], vr[4], vg[4], d1;  // lane offsets (C / residual / gate) of column block 0; d1: what block 1 adds
+  float bias_d[2];
+  float res[2][4];
+
+  __device__ __forceinline__ NtWalk(const Params& p_) : p(p_) {
+    tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    ln = lane & 31; hf = lane >> 5; wm = wave >> 1; wn = wave & 1;
+    sr = tid >> 3; sc = (tid & 7) * 4;
+    nk = (p.K + BK - 1) / BK;
+    g_rsrc = mkrsrc(LNA ? p.ln_gamma : p.a, LNA ? (int64_t)p.K * 4 : 0);
+    be_rsrc = mkrsrc(LNA ? p.ln_beta : p.a, LNA ? (int64_t)p.K * 4 : 0);
+    rows_d = 0;  // nothing to drain yet: every drain access is out of range
+    cbase_d = rbase_d = gbase_d = p.a;
+    ldc_d = 0; ncols_d = 0; keep_ab_d = false; d1 = 0;
+    bias_d[0] = bias_d[1] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { vo[e] = vr[e] = vg[e] = K_PAST; res[0][e] = res[1][e] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) accp[i][j] = zero16();
+  }
+  __device__ __forceinline__ void decode(int u, int64_t& m0, int& rows, int& n0, bool& seg, int& ncols) const {
+    const int v = xcd_remap(u, p.total);
+    const int mt = v / p.ntn, nt = v - mt * p.ntn;
+    m0 = (int64_t)mt * 128;
+    rows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
+    n0 = SW ? nt * 64 : nt * 128;
+    seg = !SW && p.split > 0 && n0 >= p.split;
+    ncols = SW ? p.H : (p.split > 0 ? (seg ? p.N - p.split : p.split) : p.N);
+    if (seg) n0 -= p.split;
+  }
+  __device__ __forceinline__ void load_unit(int u) {
+    int64_t m0; int rows, n0, ncols; bool seg;
+    decode(u, m0, rows, n0, seg, ncols);
+    const float* Wb = seg ? p.w2 : p.w;
+    const int64_t ldw = seg ? p.ldw2 : p.ldw;
+    const int wrows = SW ? 2 * p.H : ncols;
+    a_rsrc = mkrsrc(p.a + m0 * p.lda, ((int64_t)(rows - 1) * p.lda + p.K) * 4);
+    w_rsrc = mkrsrc(Wb, ((int64_t)(wrows - 1) * ldw + p.K) * 4);
+    if (LNA) { m_rsrc = mkrsrc(p.ln_mean + m0, (int64_t)rows * 4); r_rsrc = mkrsrc(p.ln_rstd + m0, (int64_t)rows * 4); }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) goff[j] = (unsigned)(((int64_t)(sr + 32 * j) * p.lda + sc) * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int rr = sr + 32 * j;
+      int wr; bool ok;
+      if (SW) { const int jj = n0 + (rr & 63); ok = jj < p.H; wr = (rr < 64 ? 0 : p.H) + jj; }
+      else { wr = n0 + rr; ok = wr < ncols; }
+      goff[4 + j] = ok ? (unsigned)(((int64_t)wr * ldw + sc) * 4) : ROW_PAST;
+    }
+  }
+  __device__ __forceinline__ void gload(int i, int kt) {
+    if (i == 0) { const int k0 = kt * BK; ka = (k0 + sc < p.K) ? (unsigned)(k0 * 4) : K_PAST; }
+    if (i < 4) {
+      stg[i] = bload4(a_rsrc, (int)(goff[i] + ka));
+      // (mean / rstd of the piece's row: re-read every step -- a load under `if (new tile)` would be a branch around a
+      //  vector-memory instruction, after which no wait can be counted)
+      if (LNA) { mu[i] = bload1(m_rsrc, (sr + 32 * i) * 4); rs[i] = bload1(r_rsrc, (sr + 32 * i) * 4); }
+      if (LNA && i == 3) { gam = bload4(g_rsrc, (int)(ka + sc * 4)); bet = bload4(be_rsrc, (int)(ka + sc * 4)); }
+    } else stg[i] = bload4(w_rsrc, (int)(goff[i] + ka));
+  }
+  __device__ __forceinline__ void lstore(int i, float* stage) {
+    float4 v = stg[i];
+    if (LNA && i < 4) {
+      v.x = fmaf((v.x - mu[i]) * rs[i], gam.x, bet.x); v.y = fmaf((v.y - mu[i]) * rs[i], gam.y, bet.y);
+      v.z = fmaf((v.z - mu[i]) * rs[i], gam.z, bet.z); v.w = fmaf((v.w - mu[i]) * rs[i], gam.w, bet.w);
+    }
+    st4(&stage[(i < 4 ? 0 : G::BREG) + (sr + 32 * (i & 3)) * LSR + sc], v);
+  }
+  // the finished tile u becomes the one to drain (straight-line code: its loads may be waited for by count)
+  __device__ __forceinline__ void retire(f32x16 (&acc)[2][2], int u) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) accp[i][j] = acc[i][j];
+    int64_t m0; int n0; bool seg;
+    decode(u, m0, rows_d, n0, seg, ncols_d);
+    const float* bias = seg ? p.bias2 : p.bias;
+    float* Cb = seg ? p.c2 : p.c;
+    ldc_d = seg ? p.ldc2 : p.ldc;
+    const __amdgpu_buffer_rsrc_t b_rsrc = mkrsrc(bias ? bias : p.a, bias ? (int64_t)(SW ? 2 * p.H : ncols_d) * 4 : 0);
+    if constexpr (SW) {
+      const int j = n0 + 32 * wn + ln;
+      const bool ok = j < p.H;
+      const unsigned cg = ok ? (unsigned)j * 4u : K_PAST;
+      bias_d[0] = bload1(b_rsrc, (int)cg);
+      bias_d[1] = bload1(b_rsrc, (int)(cg + (unsigned)p.H * 4u));
+      lane_offsets(vg, hf, p.ldg, cg);
+      lane_offsets(vo, hf, ldc_d, cg);
+      gbase_d = p.gate + m0 * p.ldg;
+      keep_ab_d = Cb != nullptr;
+      cbase_d = Cb ? Cb + m0 * ldc_d : p.gate;
+    } else {
+      const int n = n0 + 64 * wn + ln;
+      const bool ok0 = n < ncols_d, ok1 = n + 32 < ncols_d;
+      const unsigned cn = ok0 ? (unsigned)n * 4u : K_PAST;
+      d1 = ok1 ? 128u : (ok0 ? K_PAST : 0u);
+      bias_d[0] = bload1(b_rsrc, (int)cn);
+      bias_d[1] = bload1(b_rsrc, (int)(cn + d1));
+      lane_offsets(vo, hf, ldc_d, cn);
+      cbase_d = Cb + m0 * ldc_d;
+      if (EPI == EPI_RESID) {
+        lane_offsets(vr, hf, p.ldr, cn);
+        rbase_d = p.resid + m0 * p.ldr;
+        res_load(0, 0);
+        res_load(0, 1);
+      }
+    }
+  }
+  // residual values of drain group (block d, row group q) into ring slot q & 1
+  __device__ __forceinline__ void res_load(int d, int q) {
+    const int i = d & 1, j = d >> 1;
+    const __amdgpu_buffer_rsrc_t rr = group_rsrc(rbase_d, p.ldr, rows_d, 64 * wm + 32 * i + 8 * q, 0, ncols_d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) res[q & 1][e] = bload1(rr, (int)(vr[e] + (j ? d1 : 0u)));
+  }
+  // one of the 16 drain groups: block d = (i, j) (SwiGLU: i and a pair of row groups), MFMA group g
+  __device__ __forceinline__ void drain(int d, int g) {
+    if constexpr (SW) {
+      const int i = d & 1, q = 2 * (d >> 1) + (g >> 1);
+      const int rg0 = 64 * wm + 32 * i + 8 * q;
+      const __amdgpu_buffer_rsrc_t gr = group_rsrc(gbase_d, p.ldg, rows_d, rg0, 0, p.H);
+      const __amdgpu_buffer_rsrc_t ar = group_rsrc(cbase_d, ldc_d, keep_ab_d ? rows_d : 0, rg0, 0, p.H);
+      const __amdgpu_buffer_rsrc_t br = group_rsrc(cbase_d, ldc_d, keep_ab_d ? rows_d : 0, rg0, p.H, p.H);
+#pragma unroll
+      for (int e2 = 0; e2 < 2; ++e2) {
+        const int e = 2 * (g & 1) + e2;
+        const float av = accp[i][0][4 * q + e] + bias_d[0], bv = accp[i][1][4 * q + e] + bias_d[1];
+        bstore1(av * sigmoidf_(av) * bv, gr, (int)vg[e]);
+        bstore1(av, ar, (int)vo[e]);  // (zero records without keep_ab: dropped)
+        bstore1(bv, br, (int)vo[e]);
+      }
+    } else {
+      const int i = d & 1, j = d >> 1, q = g;
+      const __amdgpu_buffer_rsrc_t cr = group_rsrc(cbase_d, ldc_d, rows_d, 64 * wm + 32 * i + 8 * q, 0, ncols_d);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float v = accp[i][j][4 * q + e] + bias_d[j];
+        if (EPI == EPI_RESID) v += res[q & 1][e];
+        bstore1(v, cr, (int)(vo[e] + (j ? d1 : 0u)));
+      }
+      if (EPI == EPI_RESID) {  // refill the slot with the group two ahead
+        const int nxt = 4 * d + g + 2;
+        if (nxt < 16) res_load(nxt >> 2, nxt & 3);
+      }
+    }
+  }
+};
+
+template <int EPI, bool LNA>
+__global__ __launch_bounds__(256, 2) void gemm_nt_dkernel(Params p) {
+  using W = NtWalk<EPI, LNA>;
+  using G = Geo<32>;
+  constexpr int LSR = G::LSR;
+  constexpr bool SW = EPI == EPI_SWIGLU;
+  __shared__ __attribute__((aligned(16))) float smem[2 * G::STAGE];
+  W U(p);
+  const int Gd = gridDim.x;
+  int cu = blockIdx.x;
+  if (cu >= p.total) return;
+  // load cursor: two steps ahead of the MFMAs, across tiles
+  int lu = cu, lk = 0;
+  U.load_unit(lu);
+  auto advance = [&]() {
+    if (++lk == U.nk) {
+      lk = 0;
+      lu = lu + Gd < p.total ? lu + Gd : lu;  // past the end: the last tile again (loaded, never used)
+      U.load_unit(lu);
+    }
+  };
+  const int a_rd = (64 * U.wm + U.ln) * LSR + 16 * U.hf;
+  const int b_rd = ((SW ? 32 : 64) * U.wn + U.ln) * LSR + 16 * U.hf;
+  constexpr int a_blk = 32 * LSR, b_blk = (SW ? 64 : 32) * LSR;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) U.gload(i, lk);
+  advance();
+#pragma unroll
+  for (int i = 0; i < 8; ++i) U.lstore(i, smem);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) U.gload(i, lk);
+  advance();
+  lds_barrier();
+  int s = 0;  // steps done: LDS stage parity
+  auto frag = [&](const float* st, int s4, float (&fa)[2][4], float (&fb)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const float4 v = ld4(st + a_rd + i * a_blk + 4 * s4);
+      fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
+      const float4 w = ld4(st + G::BREG + b_rd + i * b_blk + 4 * s4);
+      fb[i][0] = w.x; fb[i][1] = w.y; fb[i][2] = w.z; fb[i][3] = w.w;
+    }
+  };
+  // one step; D >= 0: it also drains block D of the retired tile
+  auto step = [&](auto dtag) {
+    constexpr int D = decltype(dtag)::value;
+    const float* cur = smem + (s & 1) * G::STAGE;
+    float* nxt = smem + ((s + 1) & 1) * G::STAGE;
+#ifndef AMK_WALK_ABLATE
+#define AMK_WALK_ABLATE 0
+#endif
+    float a[2][4], b[2][4];
+    if (!(AMK_WALK_ABLATE & 8) || s == 0) frag(cur, 0, a, b);
+    else { for (int i = 0; i < 2; ++i) for (int x = 0; x < 4; ++x) { a[i][x] = acc[i][0][x]; b[i][x] = acc[i][1][x]; } }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float an[2][4], bn[2][4];
+      if (g + 1 < 4) {
+        if (!(AMK_WALK_ABLATE & 8)) frag(cur, g + 1, an, bn);
+        else { for (int i = 0; i < 2; ++i) for (int x = 0; x < 4; ++x) { an[i][x] = a[i][x]; bn[i][x] = b[i][x]; } }
+      }
+      if (!(AMK_WALK_ABLATE & 2)) {
+        U.lstore(2 * g, nxt); U.gload(2 * g, lk);
+        U.lstore(2 * g + 1, nxt); U.gload(2 * g + 1, lk);
+      }
+      if (g == 3) advance();
+      if (D >= 0 && !(AMK_WALK_ABLATE & 1)) U.drain(D, g);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = mfma32(a[i][x], b[j][x], (D == 0 && g == 0 && x == 0) ? zero16() : acc[i][j]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (g + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { a[i][x] = an[i][x]; b[i][x] = bn[i][x]; }
+      }
+    }
+    if (!(AMK_WALK_ABLATE & 4)) lds_barrier();
+    ++s;
+  };
+  for (;;) {
+    step(std::integral_constant<int, 0>{});
+    step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});
+    step(std::integral_constant<int, 3>{});
+    for (int kt = 4; kt < U.nk; ++kt) step(std::integral_constant<int, -1>{});
+    U.retire(acc, cu);
+    cu += Gd;
+    if (cu >= p.total) break;
+  }
+  // the last tile's results
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) U.drain(d, g);
 }
 
 // =============================================================================================================
@@ -833,7 +1130,13 @@ extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_
     p.total = (int)total;
     const dim3 grid((unsigned)total), blk(256);
     const bool b16 = dense_bk() == 16;
-#define AMK_NT(E, L) do { if (b16) hipLaunchKernelGGL((gemm_nt_kernel<16, E, L>), grid, blk, 0, st, p); else hipLaunchKernelGGL((gemm_nt_kernel<32, E, L>), grid, blk, 0, st, p); } while (0)
+    // persistent walk with the results drained under the next tile's MFMAs (K of at least four 32-deep steps);
+    // AMK_DENSE_WALK=0: one workgroup per tile
+    static int walk = -1;
+    if (walk < 0) { const char* e = getenv("AMK_DENSE_WALK"); walk = (e && e[0] == '0') ? 0 : 1; }
+    const bool use_walk = walk && !b16 && d->k > 96;
+    const dim3 wgrid((unsigned)(total > wg_slots() ? wg_slots() : total));
+#define AMK_NT(E, L) do { if (use_walk) hipLaunchKernelGGL((gemm_nt_dkernel<E, L>), wgrid, blk, 0, st, p); else if (b16) hipLaunchKernelGGL((gemm_nt_kernel<16, E, L>), grid, blk, 0, st, p); else hipLaunchKernelGGL((gemm_nt_kernel<32, E, L>), grid, blk, 0, st, p); } while (0)
     if (sw) { if (ln) AMK_NT(EPI_SWIGLU, true); else AMK_NT(EPI_SWIGLU, false); }
     else if (d->epilogue == AMK_EPI_RESID) { if (ln) AMK_NT(EPI_RESID, true); else AMK_NT(EPI_RESID, false); }
     else if (d->epilogue == AMK_EPI_BIAS) { if (ln) AMK_NT(EPI_BIAS, true); else AMK_NT(EPI_BIAS, false); }
