@@ -22,11 +22,20 @@ def _ptr(t):
 
 
 class FlatAdam:
-    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False):
+    def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
+                 capturable=False):
+        """capturable=True: the per-parameter table {active, lr / bias-correction-1, sqrt(bias-correction-2)} is
+        computed on the device from device-resident step counts and learning rate (a few tiny launches) instead of on
+        the host, so that ``step`` can be captured into a HIP graph and replayed (amk/graphs.py): nothing in it then
+        reads host memory.  The set of parameters that receive gradients must not change between replays."""
         if not reducer.on_gpu:
             raise RuntimeError("FlatAdam runs on MI355X (HIP) parameters only; use torch.optim on CPU")
+        if capturable and decoupled and weight_decay:
+            raise ValueError("FlatAdam(capturable=True): decoupled weight decay takes lr as a launch argument")
         self.red = reducer
-        self.lr, self.betas, self.eps, self.weight_decay, self.decoupled = lr, betas, eps, weight_decay, decoupled
+        self.capturable = bool(capturable)
+        self._lr = float(lr)
+        self.betas, self.eps, self.weight_decay, self.decoupled = betas, eps, weight_decay, decoupled
         self.L = _lib.load()
         self.npart = self.L.amk_opt_num_partials()
         dev = reducer.buckets[0].flat.device
@@ -56,6 +65,37 @@ class FlatAdam:
         self._tab_dev = [torch.zeros(len(self.params), 4, device=dev) for _ in range(2)]
         self._tab_done = [None, None]
         self._flip = 0
+        if self.capturable:
+            self.steps_dev = torch.zeros(len(self.params), device=dev, dtype=torch.float64)
+            self.lr_dev = torch.full((), float(lr), device=dev, dtype=torch.float64)
+            self._fired_host, self._fired_dev = None, None
+
+    @property
+    def lr(self):
+        return self._lr
+
+    @lr.setter
+    def lr(self, value):
+        self._lr = float(value)
+        if self.capturable:
+            self.lr_dev.fill_(self._lr)  # (a launch with the value as its argument: no host read at replay time)
+
+    def _device_table(self, fired):
+        """The step's table, computed on the device (capturable mode)."""
+        if self._fired_host is None or not np.array_equal(fired, self._fired_host):
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("FlatAdam: the set of parameters with gradients changed inside a HIP-graph capture; "
+                                   "run the step eagerly once (warm-up) before capturing")
+            self._fired_host = fired.copy()
+            self._fired_dev = torch.tensor(fired.astype(np.float64), device=self.steps_dev.device)
+        b1, b2 = self.betas
+        self.steps_dev += self._fired_dev
+        t = self.steps_dev.clamp(min=1.0)
+        tab = self._tab_dev[0]
+        tab[:, 0] = self._fired_dev
+        tab[:, 1] = self.lr_dev / (1.0 - torch.pow(torch.full_like(t, b1), t))
+        tab[:, 2] = torch.sqrt(1.0 - torch.pow(torch.full_like(t, b2), t))
+        return tab
 
     def step(self, max_norm=None, lr=None):
         """One optimizer step on the (already reduced) gradients; leaves every gradient zeroed and
@@ -65,21 +105,24 @@ class FlatAdam:
         red, L = self.red, self.L
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         b1, b2 = self.betas
-        # double-buffered table: the copy of step n may still be in flight when step n+1 fills its table
-        tab_h, tab_d = self._tab_host[self._flip], self._tab_dev[self._flip]
-        if self._tab_done[self._flip] is not None:
-            self._tab_done[self._flip].synchronize()  # the copy issued two steps ago has read this host buffer
-        done = self._tab_done[self._flip] = torch.cuda.Event()
-        self._flip ^= 1
         fired = np.fromiter((f for b in red.buckets for f in b.fired), dtype=bool, count=len(self.params))
-        self.steps += fired
-        t = np.maximum(self.steps, 1).astype(np.float64)
-        tab = self._tab_np[self._flip ^ 1]
-        tab[:, 0] = fired
-        tab[:, 1] = self.lr / (1.0 - b1 ** t)
-        tab[:, 2] = np.sqrt(1.0 - b2 ** t)
-        tab_d.copy_(tab_h, non_blocking=True)
-        done.record()
+        if self.capturable:
+            tab_d = self._device_table(fired)
+        else:
+            # double-buffered table: the copy of step n may still be in flight when step n+1 fills its table
+            tab_h, tab_d = self._tab_host[self._flip], self._tab_dev[self._flip]
+            if self._tab_done[self._flip] is not None:
+                self._tab_done[self._flip].synchronize()  # the copy issued two steps ago has read this host buffer
+            done = self._tab_done[self._flip] = torch.cuda.Event()
+            self._flip ^= 1
+            self.steps += fired
+            t = np.maximum(self.steps, 1).astype(np.float64)
+            tab = self._tab_np[self._flip ^ 1]
+            tab[:, 0] = fired
+            tab[:, 1] = self.lr / (1.0 - b1 ** t)
+            tab[:, 2] = np.sqrt(1.0 - b2 ** t)
+            tab_d.copy_(tab_h, non_blocking=True)
+            done.record()
         clip = float(max_norm) if max_norm else 0.0
         for k, b in enumerate(red.buckets):
             _lib.check(L.amk_sumsq_partials(_ptr(b.flat), b.flat.numel(), _ptr(self.partials[k * self.npart:]), stream),
@@ -101,7 +144,8 @@ class FlatAdam:
         for b, m, v in zip(self.red.buckets, self.m, self.v):
             if k < bi + len(b.params):
                 off = b.offsets[k - bi]
-                return dict(step=int(self.steps[k]), exp_avg=m[off:off + p.numel()].view_as(p),
+                step = int(self.steps_dev[k].item()) if self.capturable else int(self.steps[k])
+                return dict(step=step, exp_avg=m[off:off + p.numel()].view_as(p),
                             exp_avg_sq=v[off:off + p.numel()].view_as(p))
             bi += len(b.params)
         raise KeyError("parameter not managed by this optimizer")

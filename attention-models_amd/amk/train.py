@@ -56,15 +56,16 @@ class VQGANTrainStep:
         fused = next(model.parameters()).is_cuda
         self.g_red = GradReducer(model.parameters(), bucket_bytes)
         self.d_red = GradReducer(discr.parameters(), bucket_bytes)
-        # fused_optimizer (default on the GPU unless capturable): amk.optim.FlatAdam -- clip + Adam + zeroing in
-        # two passes over the reducer's flat buckets (csrc/optim.hip) instead of clip_grad_norm_ + Adam.step +
-        # zero_grad.  capturable=True: torch's Adam with the learning rate in a device tensor, so that
-        # step_body() can be captured into a HIP graph (amk/graphs.py).
-        self.fused_optimizer = (fused and not capturable) if fused_optimizer is None else bool(fused_optimizer)
+        # fused_optimizer (default on the GPU): amk.optim.FlatAdam -- clip + Adam + zeroing in two passes over the
+        # reducer's flat buckets (csrc/optim.hip) instead of clip_grad_norm_ + Adam.step + zero_grad.
+        # capturable=True: step counts and learning rate live on the device (FlatAdam(capturable=True), or torch's
+        # Adam with a tensor lr), so that step_body() can be captured into a HIP graph: see capture().
+        self.fused_optimizer = fused if fused_optimizer is None else bool(fused_optimizer)
         okw = dict(betas=betas, weight_decay=weight_decay, fused=fused)
+        self._graph = None
         if self.fused_optimizer:
-            self.g_optim = FlatAdam(self.g_red, lr=lr, betas=betas, weight_decay=weight_decay)
-            self.d_optim = FlatAdam(self.d_red, lr=lr, betas=betas, weight_decay=weight_decay)
+            self.g_optim = FlatAdam(self.g_red, lr=lr, betas=betas, weight_decay=weight_decay, capturable=capturable)
+            self.d_optim = FlatAdam(self.d_red, lr=lr, betas=betas, weight_decay=weight_decay, capturable=capturable)
         elif capturable:
             dev = next(model.parameters()).device
             okw.update(capturable=True)
@@ -122,9 +123,27 @@ class VQGANTrainStep:
         accum_steps: the losses are divided by it before backward, as accelerator.backward does with
         gradient_accumulation_steps (the logged values stay undivided)."""
         self._set_lr()
-        logs = self.step_body(img, sync, accum_steps, eta)
+        if self._graph is not None and sync and accum_steps == 1 and eta is None and img.shape == self._graph.static_inputs[0].shape:
+            logs = self._graph.replay(img)  # the whole device side of the step as one HIP-graph launch
+        else:
+            logs = self.step_body(img, sync, accum_steps, eta)
         self.global_step += 1
         return logs
+
+    def capture(self, img, warmup=2):
+        """Capture step_body() for batches shaped like `img` into a HIP graph; step() then replays it (the host
+        enqueues one launch instead of ~2500).  Needs capturable=True and a world of one rank (the reducers' RCCL
+        collectives on their side stream are not captured); `warmup` eager steps run first on the capture stream --
+        they are real optimizer steps.  release_graph() returns to eager steps."""
+        from .graphs import GraphedStep
+
+        if not self.g_red.alone or not self.d_red.alone:
+            raise RuntimeError("VQGANTrainStep.capture: data-parallel steps run eagerly")
+        self._graph = None
+        self._graph = GraphedStep(lambda x: self.step_body(x), [img], warmup=warmup)
+
+    def release_graph(self):
+        self._graph = None
 
     def _optim_step(self, opt, red, module):
         if isinstance(opt, FlatAdam):

@@ -629,30 +629,32 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dkernel(Params p) {
       fb[i][0] = w.x; fb[i][1] = w.y; fb[i][2] = w.z; fb[i][3] = w.w;
     }
   };
-  // one step; D >= 0: it also drains block D of the retired tile
+  // one step; D >= 0: it also drains block D of the retired tile.  The step's barrier sits after its third MFMA
+  // group (AMK_WALK_BARRIER_AT = 2; 3 = at the end): the fragments of the NEXT step's first group are read behind
+  // it, under the fourth group's MFMAs, so a step does not begin by waiting for LDS.  All stores of a step into the
+  // other stage happen in its groups 0-2, all its fragment reads of the current stage are issued before the barrier.
+#ifndef AMK_WALK_BARRIER_AT
+#define AMK_WALK_BARRIER_AT 2
+#endif
+  float a[2][4], b[2][4];
+  frag(smem, 0, a, b);
   auto step = [&](auto dtag) {
     constexpr int D = decltype(dtag)::value;
+    constexpr int BAT = AMK_WALK_BARRIER_AT;
     const float* cur = smem + (s & 1) * G::STAGE;
     float* nxt = smem + ((s + 1) & 1) * G::STAGE;
-#ifndef AMK_WALK_ABLATE
-#define AMK_WALK_ABLATE 0
-#endif
-    float a[2][4], b[2][4];
-    if (!(AMK_WALK_ABLATE & 8) || s == 0) frag(cur, 0, a, b);
-    else { for (int i = 0; i < 2; ++i) for (int x = 0; x < 4; ++x) { a[i][x] = acc[i][0][x]; b[i][x] = acc[i][1][x]; } }
+    auto mv = [&](int i) { U.lstore(i, nxt); U.gload(i, lk); };
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       float an[2][4], bn[2][4];
-      if (g + 1 < 4) {
-        if (!(AMK_WALK_ABLATE & 8)) frag(cur, g + 1, an, bn);
-        else { for (int i = 0; i < 2; ++i) for (int x = 0; x < 4; ++x) { an[i][x] = a[i][x]; bn[i][x] = b[i][x]; } }
-      }
-      if (!(AMK_WALK_ABLATE & 2)) {
-        U.lstore(2 * g, nxt); U.gload(2 * g, lk);
-        U.lstore(2 * g + 1, nxt); U.gload(2 * g + 1, lk);
-      }
-      if (g == 3) advance();
-      if (D >= 0 && !(AMK_WALK_ABLATE & 1)) U.drain(D, g);
+      if (g + 1 < 4) frag(cur, g + 1, an, bn);
+      if (BAT == 3) { mv(2 * g); mv(2 * g + 1); }
+      else if (g == 0) { mv(0); mv(1); mv(2); }
+      else if (g == 1) { mv(3); mv(4); mv(5); }
+      else if (g == 2) { mv(6); mv(7); }
+      if (g == BAT || (BAT == 3 && g == 3)) { if (g == (BAT == 3 ? 3 : 2)) advance(); }
+      if (D >= 0) U.drain(D, g);
+      if (BAT == 2 && g == 3) frag(nxt, 0, an, bn);  // (behind the barrier below group 2)
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
@@ -663,14 +665,15 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_dkernel(Params p) {
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      if (g + 1 < 4) {
+      if (BAT == 2 && g == 2) lds_barrier();
+      if (g + 1 < 4 || BAT == 2) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
           for (int x = 0; x < 4; ++x) { a[i][x] = an[i][x]; b[i][x] = bn[i][x]; }
       }
     }
-    if (!(AMK_WALK_ABLATE & 4)) lds_barrier();
+    if (BAT == 3) { lds_barrier(); frag(nxt, 0, a, b); }
     ++s;
   };
   for (;;) {
@@ -957,22 +960,33 @@ __global__ AMK_DENSE_BOUNDS(BK) void gemm_tn_kernel(Params p) {
 }
 
 // C = sum over chunks of ws (in chunk order).  Elements [0, split * K) go to c (rows of ldc), the rest to c2.
+// One thread per 16-byte piece; the chunks are read eight at a time (independent loads in flight) and added in order.
 __global__ __launch_bounds__(256) void tn_reduce_kernel(Params p, float* dbias_out) {
   const int64_t total4 = (int64_t)p.N * p.K / 4;
   const int64_t slab = (int64_t)p.N * p.K;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
-    float4 s = ld4(p.ws + 4 * i);
-    for (int c = 1; c < p.nchunk; ++c) {
-      const float4 v = ld4(p.ws + c * slab + 4 * i);
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total4) {
+    const float* src = p.ws + 4 * i;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c = 0;
+    for (; c + 8 <= p.nchunk; c += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = ld4(src + (c + j) * slab);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+    }
+    for (; c < p.nchunk; ++c) {
+      const float4 v = ld4(src + c * slab);
       s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
     }
     const int64_t e = 4 * i;
-    int64_t row = e / p.K;
+    const int64_t row = e / p.K;
     const int col = (int)(e - row * p.K);
     if (p.split > 0 && row >= p.split) st4(p.c2 + (row - p.split) * p.ldc2 + col, s);
     else st4(p.c + row * p.ldc + col, s);
   }
-  if (dbias_out && blockIdx.x == 0) {
+  if (dbias_out && blockIdx.x == gridDim.x - 1) {
     for (int n = threadIdx.x; n < p.N; n += 256) {
       float s = 0.f;
       for (int c = 0; c < p.nchunk; ++c) s += p.dbias[(int64_t)c * p.N + n];
@@ -1196,7 +1210,7 @@ extern "C" int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_
   if (chunks > 1) {
     const int64_t items = (int64_t)d->n * d->k / 4;
     const int64_t blocks = (items + 255) / 256;
-    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, p, dbias_out);
+    hipLaunchKernelGGL(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, dbias_out);
     AMK_CHECK_LAUNCH("amk_gemm_f32(TN reduce)");
   }
   return AMK_OK;

@@ -49,6 +49,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational shared-forward variant")
+    ap.add_argument("--no-graph", action="store_true", help="enqueue every step launch by launch instead of replaying one HIP graph")
     return ap.parse_args()
 
 
@@ -263,7 +264,11 @@ def main():
     init_state = {k: v.detach().clone() for k, v in model.state_dict().items()} if rank == 0 else None
     model = model.to(dev)
     discr = NLayerDiscriminator(3, 64, 3).to(dev)
-    trainer = VQGANTrainStep(model, discr)
+    # one rank: the device side of a step (both phases, both optimizers) is captured into a HIP graph after the
+    # warm-up and replayed -- the host then enqueues one launch per step instead of ~2500 (tools/host_vs_gpu.py:
+    # 92.7 ms of host work per step in round 2); N ranks: eager steps (the reducers' RCCL collectives run on a side stream)
+    use_graph = world == 1 and not args.no_graph
+    trainer = VQGANTrainStep(model, discr, capturable=use_graph)
     g = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, VIT["img_size"], VIT["img_size"], generator=g).to(dev)
 
@@ -285,7 +290,9 @@ def main():
     note(f"rank {rank}/{world}: model built, batch {args.batch}/GPU")
     for _ in range(args.warmup):
         trainer.step(imgs)
-    note("warm-up done")
+    if use_graph:
+        trainer.capture(imgs)
+    note("warm-up done" + (" (step captured into a HIP graph)" if use_graph else ""))
     # ---- the headline: EXACTLY --steps steps, no instrumentation, barrier + synchronize on both sides
     dt, logs = timed_steps(args.steps)
     if world > 1:
@@ -300,6 +307,7 @@ def main():
     in_situ, n_inst = {}, 0
     if rank == 0 and world == 1 and not args.no_kernels:
         n_inst = max(2, min(5, args.steps))
+        trainer.release_graph()  # the events are recorded launch by launch: eager steps
         amk_ops.KERNEL_EVENTS = {}
         timed_steps(n_inst)
         in_situ = amk_ops.kernel_event_summary(amk_ops.KERNEL_EVENTS)
@@ -307,10 +315,14 @@ def main():
         note("instrumented pass done")
 
     def variant(setup, teardown, what):
+        trainer.release_graph()
         setup()
         for _ in range(2):
             trainer.step(imgs)
+        if use_graph:
+            trainer.capture(imgs)
         dv, _ = timed_steps(args.steps)
+        trainer.release_graph()
         teardown()
         return {"value": args.batch * args.steps / dv, "unit": "images/s", "ms_per_step": dv / args.steps * 1e3, "what": what}
 

@@ -280,3 +280,22 @@ def _graph_replay_case(device, copy, GraphedStep, ViTVQGAN, NLayerDiscriminator,
             assert float((le[k] - lg[k]).abs()) <= 2e-5 * max(1.0, float(le[k].abs())), k
     for (n, p), q in zip(model.named_parameters(), model2.parameters()):
         assert float((p - q).abs().max()) <= 2e-5 * max(1.0, float(p.abs().max())), n
+    # the same through VQGANTrainStep.capture(): step() replays the graph (what bench.py times on one rank)
+    torch.manual_seed(0)
+    model3 = ViTVQGAN(vit, dict(codebook_size=64, codebook_dim=32)).to(device)
+    discr3 = NLayerDiscriminator(3, 8, 3).to(device)
+    model3.load_state_dict(model2.state_dict())
+    discr3.load_state_dict(discr2.state_dict())
+    model4, discr4 = copy.deepcopy(model3), copy.deepcopy(discr3)
+    e2 = VQGANTrainStep(model3, discr3, warmup_steps=1, gp_lambda=0.0, capturable=True)
+    c2 = VQGANTrainStep(model4, discr4, warmup_steps=1, gp_lambda=0.0, capturable=True)
+    e2.step(imgs)
+    c2.step(imgs)            # eager: also fixes the set of parameters with gradients
+    c2.capture(imgs, warmup=0)
+    for _ in range(2):
+        le, lc = e2.step(imgs), c2.step(imgs)
+        for k in le:
+            assert float((le[k] - lc[k]).abs()) <= 2e-5 * max(1.0, float(le[k].abs())), k
+    assert c2.global_step == e2.global_step == 3
+    for (n, p), q in zip(model3.named_parameters(), model4.parameters()):
+        assert float((p - q).abs().max()) <= 2e-5 * max(1.0, float(p.abs().max())), n
