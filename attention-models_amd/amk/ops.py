@@ -383,20 +383,20 @@ class _VQLookup(torch.autograd.Function):
         dz = torch.empty_like(zf)
         L = _lib.load()
         if DETERMINISTIC_ATTENTION_BACKWARD or torch.are_deterministic_algorithms_enabled():
-            # reproducible codebook gradient: per-row contributions, added in a fixed order (torch's deterministic
-            # index_add_ sorts by index) instead of the kernel's f32 atomics
+            # reproducible codebook gradient: per-row contributions, added in a fixed order instead of the kernel's
+            # f32 atomics
             ge = torch.empty_like(zf)
             rc = L.amk_vq_lookup_bwd_rows(
                 _ptr(zf), _ptr(cb), _ptr(zn), _ptr(zq), _ptr(idx), _ptr(g_out), _ptr(g_loss),
                 float(ctx.beta), N, K, C, _ptr(dz), _ptr(ge), _stream(),
             )
             _lib.check(rc, "amk_vq_lookup_bwd_rows")
-            was = torch.are_deterministic_algorithms_enabled()
-            torch.use_deterministic_algorithms(True)
-            try:
-                dcb = torch.zeros_like(cb).index_add_(0, idx.clamp(0, K - 1), ge)
-            finally:
-                torch.use_deterministic_algorithms(was)
+            # ordered sum per code without touching torch's global determinism switches: rows sorted by code
+            # (stable: equal codes keep their row order), then one sequential sum per segment
+            flat_idx = idx.clamp(0, K - 1)
+            srt, order = torch.sort(flat_idx, stable=True)
+            bounds = torch.searchsorted(srt, torch.arange(K + 1, device=srt.device, dtype=srt.dtype))
+            dcb = torch.segment_reduce(ge.index_select(0, order), "sum", offsets=bounds, axis=0, unsafe=True)
             return dz.view(ctx.z_shape), dcb, None
         dcb = torch.empty_like(cb)
         rc = L.amk_vq_lookup_bwd(

@@ -132,6 +132,22 @@ def kernel_rooflines(B, dev, iters):
     t = time_launches(lambda: ops.vq_lookup(z, E, 0.25), iters)
     out.append(dict(kernel="vq_lookup_fwd (prep+argmin+finalize)", launches_per_step=2, avg_ms=t * 1e3,
                     flop=2.0 * N * K * C, note="2*N*K*C"))
+    # head dims 32 and 128 (csrc/attn_generic.hip: plain forward, two recompute kernels backward) at the same token
+    # count and h * d = 512: not on the ViT-VQGAN path, reported so that every shipped kernel has a number
+    for Dg in (32, 128):
+        Hg = 512 // Dg
+        mkg = lambda: torch.randn(B, T, Hg, Dg, generator=g).to(dev).permute(0, 2, 1, 3)
+        qg, kg, vg, dog = mkg(), mkg(), mkg(), mkg()
+        sg = Dg ** -0.5
+        qg, kg, vg, og, stg, _ = ops._attn_forward(qg, kg, vg, None, None, sg)
+        dqg, dkg, dvg = (torch.empty_like(qg) for _ in range(3))
+        coreg = 4.0 * B * Hg * T * T * Dg
+        t = time_launches(lambda: ops._attn_forward(qg, kg, vg, None, None, sg), iters)
+        out.append(dict(kernel=f"attn_fwd_gen_kernel<{Dg}>", launches_per_step=0, avg_ms=t * 1e3, flop=coreg,
+                        note=f"4*B*h*I*J*d at head dim {Dg}, {Hg} heads"))
+        t = time_launches(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg), iters)
+        out.append(dict(kernel=f"attn_bwd_gen_kernels<{Dg}> (delta + dkdv + dq)", launches_per_step=0, avg_ms=t * 1e3,
+                        flop=2 * coreg, note="8*B*h*I*J*d credited (recomputed S and dP not credited)"))
     for r in out:
         r["tflops"] = r["flop"] / (r["avg_ms"] * 1e-3) / 1e12
         r["frac_of_f32_mfma_peak"] = r["tflops"] / F32_MFMA_PEAK_TFLOPS
@@ -225,6 +241,9 @@ def latest_pmc_digest():
 
 def main():
     args = parse()
+    # dmabuf IPC is what RCCL needs on this pool; set before the first HIP call, for BOTH launch modes (the driver's
+    # torch.distributed.run launch never passes through self_launch)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         return self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -443,6 +462,10 @@ def main():
                 "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": dom["frac_of_f32_mfma_peak"],
                 "traffic": traffic, "traffic_source": traffic_source,
                 "avg_launch_ms": dom["avg_ms"], "flop_per_launch": dom["flop"], "measured": source,
+                # BASELINE's metric is "attn+VQ kernel %roofline": every hand-written attention / VQ kernel of the step,
+                # same measurement, so that the fractions survive in the parsed line and not only in extra keys
+                "kernels": [dict(kernel=r["kernel"], frac=r["frac_of_f32_mfma_peak"], achieved=r["tflops"],
+                                 avg_launch_ms=r["avg_ms"], launches_per_step=r["launches_per_step"]) for r in timed],
             }
             line["kernels_in_step"] = timed
         line.update(variants)
@@ -454,6 +477,9 @@ def main():
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
     if world > 1:
+        # teardown in a defined order: rank 0's post-headline work (kernel micro-benchmarks, the JSON line) is done
+        # before any rank leaves the group -- the other ranks wait here instead of tearing RCCL down under it
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -86,6 +86,16 @@ def _two_rank_worker(rank, world, port, out_dir):
     try:
         torch.manual_seed(50 + rank)  # different init per rank: the broadcast must fix it
         net = nn.Sequential(SoftmaxAttention(128, 2, 64), nn.Linear(128, 16)).to(dev)
+        # overlap on the GPU branch: when the gradient of the FIRST-registered parameter lands (the last one backward
+        # produces) -- seen by a hook registered BEFORE the reducer's own, so before the reducer has counted it --
+        # bucket 0 (the last-registered parameters) must already have left on the side stream
+        seen = {}
+        first = next(iter(net.parameters()))
+
+        def _note(p):
+            seen.setdefault("launched", list(red.launch_order))   # (a hook must return None)
+
+        first.register_post_accumulate_grad_hook(_note)
         red = GradReducer(net.parameters(), bucket_bytes=64 << 10)
         assert red.on_gpu and not red.alone and len(red.buckets) > 1
         opt = FlatAdam(red, lr=1e-2)
@@ -95,9 +105,13 @@ def _two_rank_worker(rank, world, port, out_dir):
         y = torch.randn(4, 40, 16, generator=g)[2 * rank:2 * rank + 2].to(dev)
         red.begin(sync=True)
         ((net(x) - y) ** 2).mean().backward()
+        seen["before_finish"] = list(red.launch_order)
         red.finish()
         grads = [p.grad.detach().cpu().clone() for p in net.parameters()]
         order = list(red.launch_order)
+        assert seen["launched"] and seen["launched"][0] == 0, f"bucket 0 had not left when backward reached its last gradient: {seen}"
+        assert len(red.buckets) - 1 not in seen["launched"], "the first-registered parameter's bucket cannot have left before its gradient"
+        assert len(seen["before_finish"]) == len(red.buckets), "every bucket leaves inside backward when all parameters get gradients"
         opt.step(max_norm=1.0)
         torch.cuda.synchronize()
         torch.save(dict(grads=grads, order=order, params=[p.detach().cpu().clone() for p in net.parameters()]),

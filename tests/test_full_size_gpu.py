@@ -136,3 +136,58 @@ def test_cross_attention_config4_shape_slices_vs_oracle(device):
         assert_close(gq[b:b + 1, h:h + 1], wq, 2e-5, f"dq[{b},{h}]")
         assert_close(gk[b:b + 1, h:h + 1], wk, 2e-5, f"dk[{b},{h}]")
         assert_close(gv[b:b + 1, h:h + 1], wv, 2e-5, f"dv[{b},{h}]")
+
+
+def test_vitvqgan_config2_full_size_train_step(device):
+    """BASELINE.json configs[2] -- the benchmarked workload -- as ONE whole GAN train step at its own size (dim 256,
+    patch 8, 1024 tokens, depth 6 + 6, codebook 8192 x 32, PatchGAN discriminator with gradient penalty), batch 8:
+    finite losses; every generator and discriminator parameter receives a finite non-zero gradient (read from Adam's
+    first moment, the gradients themselves are zeroed inside the fused update); and, on the reproducible paths
+    (attention backward with ordered dq, codebook gradient by ordered sums), two steps from identical state give
+    bitwise identical generator gradients / losses up to what the vendor's convolution weight gradients allow --
+    the generator phase's inputs come through the discriminator, so the comparison is bitwise for the losses of the
+    discriminator phase and the generator's forward, and 1e-5 relative for parameters after the step."""
+    import copy
+
+    import bench
+    from amk import ops
+    from amk.models import ViTVQGAN
+    from amk.models.discriminator import NLayerDiscriminator
+    from amk.optim import FlatAdam
+    from amk.train import VQGANTrainStep
+
+    torch.manual_seed(0)
+    model = ViTVQGAN(bench.VIT, bench.CODEBOOK).to(device)
+    discr = NLayerDiscriminator(3, 64, 3).to(device)
+    model2, discr2 = copy.deepcopy(model), copy.deepcopy(discr)
+    imgs = torch.rand(8, 3, 256, 256, generator=torch.Generator().manual_seed(3)).to(device)
+    eta = torch.rand(8, 1, 1, 1, generator=torch.Generator().manual_seed(4)).to(device)
+    old = ops.DETERMINISTIC_ATTENTION_BACKWARD
+    ops.DETERMINISTIC_ATTENTION_BACKWARD = True
+    try:
+        runs = []
+        for m, d in ((model, discr), (model2, discr2)):
+            tr = VQGANTrainStep(m, d, warmup_steps=1)
+            logs = tr.step(imgs, eta=eta)
+            runs.append((tr, {k: v.detach().clone() for k, v in logs.items()}))
+    finally:
+        ops.DETERMINISTIC_ATTENTION_BACKWARD = old
+    (tr, logs), (tr2, logs2) = runs
+    for k, v in logs.items():
+        assert torch.isfinite(v).all(), k
+    assert set(logs) == {"g_loss", "l1", "l2", "codebook_loss", "loss", "d_loss"}
+    # every parameter got a gradient: Adam's first moment after one step is (1 - beta1) * clipped gradient
+    for opt, mod, what in ((tr.g_optim, model, "generator"), (tr.d_optim, discr, "discriminator")):
+        assert isinstance(opt, FlatAdam)
+        for n, p in mod.named_parameters():
+            st = opt.state_of(p)
+            assert st["step"] == 1, f"{what} {n}: no optimizer step (no gradient)"
+            m1 = st["exp_avg"]
+            assert torch.isfinite(m1).all() and float(m1.abs().max()) > 0.0, f"{what} {n}: zero or non-finite gradient"
+            assert torch.isfinite(p).all(), f"{what} {n}"
+    # repeatability
+    assert torch.equal(logs["d_loss"], logs2["d_loss"]), "discriminator phase: same state, same losses"
+    for k in ("l1", "l2", "codebook_loss"):
+        assert torch.equal(logs[k], logs2[k]), k
+    for (n, p), q in zip(model.named_parameters(), model2.parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-5 * max(1.0, float(p.detach().abs().max())) + 2.1e-4, n  # (+ 2 lr: an Adam sign flip)

@@ -237,3 +237,11 @@ def test_reproducible_codebook_gradient(device, N, K, C):
         torch.use_deterministic_algorithms(False)
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
     assert_close(g1[1], gE_r, TOL, "grad codebook (ordered)")
+    # the ordered path must leave torch's global switches as it found them (warn-only mode stays warn-only)
+    torch.use_deterministic_algorithms(True, warn_only=True)
+    try:
+        g3 = grads()
+        assert torch.are_deterministic_algorithms_enabled() and torch.is_deterministic_algorithms_warn_only_enabled()
+    finally:
+        torch.use_deterministic_algorithms(False)
+    assert torch.equal(g3[1], g1[1])
