@@ -101,33 +101,51 @@ class MUSE(nn.Module):
         return F.cross_entropy(logits.transpose(1, 2), tgt, ignore_index=self.ignore_index)
 
     @torch.no_grad()
-    def generate(self, text_hidden, timesteps=18):
+    def generate(self, text_hidden, timesteps=18, gumbel=None):
         ctx = self._context(text_hidden)
-        dev = ctx.device
-        B, n = ctx.shape[0], self.vq.num_patches
-        ids = torch.full((B, n), self.mask_token_id, dtype=torch.long, device=dev)
-        scores = torch.zeros(B, n, device=dev)
-        mask = torch.zeros(B, n, dtype=torch.bool, device=dev)
-        null_ctx = torch.zeros_like(ctx)
-        for step, t in enumerate(torch.linspace(0, 1, timesteps, device=dev)):
-            steps_until_x0 = timesteps - 1 - step
-            n_masked = max(int((cosine_schedule(t) * n).item()), 1)
-            low = torch.argsort(scores, dim=-1)[:, :n_masked]          # least confident tokens
-            mask.scatter_(1, low, True)
-            ids = ids.masked_fill(mask, self.mask_token_id)
-            logits = self.decoder(ids, context=ctx)                     # two decoder passes per step:
-            null_logits = self.decoder(ids, context=null_ctx)           # conditional + unconditional
-            temperature = 1 * (steps_until_x0 / timesteps)
-            if self.fused_sampling:
-                # CFG (scale 3) + softmax + top-(1-p) filter + Gumbel-argmax + score gather + masked write:
-                # one pass over the logits (csrc/sample.hip) instead of the op chain below
-                scores = ops.sample_step(logits, ids, mask=mask, null_logits=null_logits, cfg_scale=3.0,
-                                         tau=temperature, p=0.9)
-            else:
-                scaled = null_logits + 3 * (logits - null_logits)       # classifier-free guidance, scale 3
-                probs = F.softmax(scaled, dim=-1)
-                pred = F.gumbel_softmax(filter_logits(scaled, p=0.9), tau=temperature, hard=False, dim=-1).argmax(dim=-1)
-                ids[mask] = pred[mask]
-                scores = probs.gather(2, pred.unsqueeze(-1)).squeeze(-1)
-            mask = torch.zeros_like(mask)
+        ids = parallel_decode(self.decoder, ctx, self.mask_token_id, self.vq.num_patches, timesteps,
+                              fused_sampling=self.fused_sampling, gumbel=gumbel)
         return self.vq.decode_indices(ids)
+
+
+@torch.no_grad()
+def parallel_decode(decoder, ctx, mask_token_id, n, timesteps=18, fused_sampling=True, gumbel=None, trace=None):
+    """The masked-token parallel decode of MUSE.generate (models/muse.py:180-236): per step, re-mask the least
+    confident tokens (cosine schedule), run the decoder with and without the text context, sample every masked
+    token.  gumbel: explicit noise (timesteps, B, n, V) in place of the sampler's own (tests replay the reference's
+    draw); trace: a list that receives the ids entering the decoder at every step.  Returns the final ids (B, n)."""
+    dev = ctx.device
+    B = ctx.shape[0]
+    ids = torch.full((B, n), mask_token_id, dtype=torch.long, device=dev)
+    scores = torch.zeros(B, n, device=dev)
+    mask = torch.zeros(B, n, dtype=torch.bool, device=dev)
+    null_ctx = torch.zeros_like(ctx)
+    for step, t in enumerate(torch.linspace(0, 1, timesteps, device=dev)):
+        steps_until_x0 = timesteps - 1 - step
+        n_masked = max(int((cosine_schedule(t) * n).item()), 1)
+        low = torch.argsort(scores, dim=-1)[:, :n_masked]          # least confident tokens
+        mask.scatter_(1, low, True)
+        ids = ids.masked_fill(mask, mask_token_id)
+        if trace is not None:
+            trace.append(ids.clone())
+        logits = decoder(ids, context=ctx)                          # two decoder passes per step:
+        null_logits = decoder(ids, context=null_ctx)                # conditional + unconditional
+        temperature = 1 * (steps_until_x0 / timesteps)
+        noise = gumbel[step] if gumbel is not None else None
+        if fused_sampling:
+            # CFG (scale 3) + softmax + top-(1-p) filter + Gumbel-argmax + score gather + masked write:
+            # one pass over the logits (csrc/sample.hip) instead of the op chain below
+            scores = ops.sample_step(logits, ids, mask=mask, null_logits=null_logits, cfg_scale=3.0,
+                                     tau=temperature, p=0.9, gumbel=noise)
+        else:
+            scaled = null_logits + 3 * (logits - null_logits)       # classifier-free guidance, scale 3
+            probs = F.softmax(scaled, dim=-1)
+            filt = filter_logits(scaled, p=0.9)
+            if noise is None:
+                pred = F.gumbel_softmax(filt, tau=temperature, hard=False, dim=-1).argmax(dim=-1)
+            else:
+                pred = F.softmax((filt + noise) / temperature, dim=-1).argmax(dim=-1)
+            ids[mask] = pred[mask]
+            scores = probs.gather(2, pred.unsqueeze(-1)).squeeze(-1)
+        mask = torch.zeros_like(mask)
+    return ids

@@ -434,12 +434,14 @@ _SAMPLE_CALLS = 0
 
 
 def sample_step(logits, ids, mask=None, null_logits=None, cfg_scale=3.0, tau=1.0, p=0.9, gumbel=None, seed=None,
-                unmasked_score=None):
+                unmasked_score=None, generator=None):
     """One step of the parallel decode on (B, T, V) logits, in one pass (csrc/sample.hip): classifier-free
     guidance, softmax, top-(1-p) filter, Gumbel-argmax at temperature tau, chosen probability.
     ids (B, T) int64 is updated IN PLACE where mask (B, T) bool is True (everywhere without a mask);
-    returns scores (B, T).  gumbel: explicit noise (B, T, V) -- else drawn in-kernel (Philox; seeded from
-    torch's generator so that torch.manual_seed reproduces a run)."""
+    returns scores (B, T).  gumbel: explicit noise (B, T, V) -- else drawn in-kernel: Philox4x32-10 keyed by the seed
+    and stream offset of torch's CUDA generator (`generator`, default the device's), which is advanced by the call, so
+    torch.manual_seed reproduces a run; an explicit `seed` uses this module's call counter as the offset instead.
+    Ties at the keep-th largest logit: every logit >= that value is kept (the reference's topk keeps exactly k)."""
     import math
 
     global _SAMPLE_CALLS
@@ -452,11 +454,18 @@ def sample_step(logits, ids, mask=None, null_logits=None, cfg_scale=3.0, tau=1.0
         raise RuntimeError("sample_step: ids must be a contiguous int64 tensor (updated in place)")
     m8 = mask.to(torch.uint8).contiguous() if mask is not None else None
     scores = torch.empty((B, T), device=logits.device, dtype=torch.float32)
-    if seed is None:
-        seed = int(torch.initial_seed()) & ((1 << 63) - 1)
-    _SAMPLE_CALLS += 1
+    if seed is not None:
+        _SAMPLE_CALLS += 1          # explicit seed: the stream position is this module's call counter
+        offset = _SAMPLE_CALLS
+    else:
+        # torch's generator for this device supplies the Philox key and stream position, and is advanced past what
+        # this call consumes: torch.manual_seed(s); generate(); torch.manual_seed(s); generate() repeats the samples
+        gen = generator if generator is not None else torch.cuda.default_generators[logits.device.index or 0]
+        seed = int(gen.initial_seed()) & ((1 << 63) - 1)
+        offset = int(gen.get_offset())
+        gen.set_offset(offset + 4 * ((B * T * V + 3) // 4))
     L = _lib.load()
-    rc = L.amk_sample_step(_ptr(logits), _ptr(null_logits), float(cfg_scale), _ptr(gumbel), seed, _SAMPLE_CALLS, float(tau),
+    rc = L.amk_sample_step(_ptr(logits), _ptr(null_logits), float(cfg_scale), _ptr(gumbel), seed, offset, float(tau),
                            B * T, V, math.ceil((1 - p) * V), _ptr(m8), -1.0 if unmasked_score is None else float(unmasked_score),
                            _ptr(ids), _ptr(scores), _stream())
     _lib.check(rc, "amk_sample_step")

@@ -401,6 +401,41 @@ def gen_muse_decoder(mods, meta):
                                       n_params=sum(p.numel() for p in m.parameters()))
 
 
+def gen_muse_generate(mods, meta):
+    """The parallel decode loop itself: the reference's MUSE.generate (models/muse.py:180-239) called as an unbound
+    function on a namespace holding the reference's BidirectionalDecoder, a synthetic-context text encoder (SURVEY.md
+    section 8c: CLIP needs a download) and an identity `vq` -- so the loop that runs is the reference's own text:
+    cosine schedule, argsort / scatter masking, the two decoder passes, guidance, softmax, filter_logits,
+    F.gumbel_softmax, gather.  Stored: the ids entering the decoder at every step (recorded by the decoder wrapper),
+    the final ids, and the Gumbel noise the loop drew (re-drawn from the same seed: F.gumbel_softmax is the loop's
+    only consumer of the global generator)."""
+    muse = importlib.import_module("models.muse")
+    cfg = dict(dim=64, codebook_size=256, n_heads=2, d_head=64, depth=2, mult=4, dropout=0.0, num_patches=16)
+    dec = muse.BidirectionalDecoder(**cfg)
+    randomize_(dec, 91)
+    dec.eval()
+    b, timesteps, seed = 2, 6, 4242
+    ctx = seeded((b, 7, 64), 1102)
+    seen = []
+
+    def decoder(ids, context=None, context_mask=None):
+        seen.append(ids.clone())
+        return dec(ids, context=context, context_mask=context_mask)
+
+    ns = types.SimpleNamespace(vq=types.SimpleNamespace(num_patches=cfg["num_patches"], decode_indices=lambda ids: ids),
+                               text_encoder=lambda texts, device=None: (ctx, ctx), mask_token_id=cfg["codebook_size"],
+                               decoder=decoder)
+    torch.manual_seed(seed)
+    with torch.no_grad():
+        final_ids = muse.MUSE.generate(ns, ["a", "b"], timesteps=timesteps, device="cpu")
+    assert len(seen) == 2 * timesteps and all(torch.equal(seen[2 * t], seen[2 * t + 1]) for t in range(timesteps))
+    torch.manual_seed(seed)
+    noise = torch.stack([-torch.empty(b, cfg["num_patches"], cfg["codebook_size"]).exponential_().log() for _ in range(timesteps)])
+    arrays = dict(np_state(dec), context=ctx.numpy(), final_ids=final_ids.numpy(), gumbel=noise.numpy(),
+                  ids_in=torch.stack([seen[2 * t] for t in range(timesteps)]).numpy())
+    meta["muse_generate_small"] = dict(bytes=save("muse_generate_small", **arrays), cfg=cfg, timesteps=timesteps, seed=seed)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -426,6 +461,7 @@ def main():
     gen_vit(mods, meta)
     gen_vit_moe(mods, meta)
     gen_muse_decoder(mods, meta)
+    gen_muse_generate(mods, meta)
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     total = sum(v["bytes"] for v in meta.values() if isinstance(v, dict) and "bytes" in v)

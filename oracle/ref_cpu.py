@@ -373,3 +373,26 @@ def sampling_step(logits, ids, mask, gumbel, tau, null_logits=None, cfg_scale=3.
     if unmasked_score is not None:
         scores = scores.masked_fill(~mask, unmasked_score)
     return ids, scores
+
+
+def muse_generate(ctx, w, n_heads, d_head, depth, num_patches, mask_token_id, timesteps, gumbel):
+    """MUSE.generate (models/muse.py:180-239) restated on the functions above, with the loop's Gumbel noise given
+    (timesteps, B, n, V).  Returns (ids entering the decoder at each step, final ids)."""
+    import math
+
+    b, n = ctx.shape[0], num_patches
+    ids = torch.full((b, n), mask_token_id, dtype=torch.long)
+    scores = torch.zeros(b, n)
+    mask = torch.zeros(b, n, dtype=torch.bool)
+    seen = []
+    for step, t in enumerate(torch.linspace(0, 1, timesteps)):
+        steps_until_x0 = timesteps - 1 - step
+        n_masked = max(int((torch.cos(t * math.pi / 2) * n).item()), 1)
+        mask.scatter_(1, torch.argsort(scores, dim=-1)[:, :n_masked], True)
+        ids = ids.masked_fill(mask, mask_token_id)
+        seen.append(ids.clone())
+        logits = bidirectional_decoder(ids, ctx, w, n_heads, d_head, depth)
+        null_logits = bidirectional_decoder(ids, torch.zeros_like(ctx), w, n_heads, d_head, depth)
+        ids, scores = sampling_step(logits, ids, mask, gumbel[step], 1 * (steps_until_x0 / timesteps), null_logits=null_logits)
+        mask = torch.zeros_like(mask)
+    return seen, ids

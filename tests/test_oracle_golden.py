@@ -249,3 +249,23 @@ def test_vqgan_codebook_oracle_matches_reference_fixture():
     B = z.shape[0]
     emb = ref_cpu.vqgan_indices_to_embeddings(idx.view(B, -1), E.detach())
     assert_close(emb, fx["emb"], 0.0, "emb")
+
+
+def test_muse_generate_loop_follows_the_reference():
+    """The oracle's restatement of the parallel decode loop (ref_cpu.muse_generate over ref_cpu.sampling_step and
+    ref_cpu.bidirectional_decoder) against the fixture produced by the reference's own MUSE.generate
+    (oracle/gen_golden.py:gen_muse_generate): the ids entering the decoder at every step and the final ids."""
+    import json
+    import os
+
+    from util import GOLDEN
+
+    fx = load_golden("muse_generate_small")
+    meta = json.load(open(os.path.join(GOLDEN, "golden_meta.json")))["muse_generate_small"]
+    cfg = meta["cfg"]
+    w = weights_of(fx)
+    seen, final = ref_cpu.muse_generate(torch.from_numpy(fx["context"]), w, cfg["n_heads"], cfg["d_head"], cfg["depth"],
+                                        cfg["num_patches"], cfg["codebook_size"], meta["timesteps"], torch.from_numpy(fx["gumbel"]))
+    for t, ids in enumerate(seen):
+        assert torch.equal(ids, torch.from_numpy(fx["ids_in"][t])), f"decoder input at step {t}"
+    assert torch.equal(final, torch.from_numpy(fx["final_ids"]))

@@ -52,6 +52,14 @@ def test_sample_step_in_kernel_noise(device):
     ids2 = torch.zeros_like(ids)
     ops.sample_step(logits, ids2, tau=1.0, p=0.5, seed=123)
     assert not torch.equal(ids, ids2)          # the call counter advances the stream
+    # torch's generator drives the stream when no seed is given: manual_seed repeats the samples, and a call advances it
+    a, b, c = (torch.zeros_like(ids) for _ in range(3))
+    torch.manual_seed(77)
+    ops.sample_step(logits, a, tau=1.0, p=0.5)
+    ops.sample_step(logits, b, tau=1.0, p=0.5)
+    torch.manual_seed(77)
+    ops.sample_step(logits, c, tau=1.0, p=0.5)
+    assert torch.equal(a, c) and not torch.equal(a, b)
     s = logits[0, 0, keep].double()
     want = torch.softmax(s, 0)
     freq = torch.stack([(ids == k).double().mean() for k in keep])
@@ -90,3 +98,28 @@ def test_maskgit_model(device):
         m.fused_sampling = fused
         out = m.generate(batch=2, timesteps=6)
         assert tuple(out.shape) == (2, 3, 32, 32) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_parallel_decode_loop_matches_the_reference_run(device, fused):
+    """The decode loop on the GPU (amk.models.muse.parallel_decode: HIP attention in the decoder, amk_sample_step for
+    the sampling chain) against the fixture the reference's own MUSE.generate produced (tests/golden/
+    muse_generate_small.npz, oracle/gen_golden.py:gen_muse_generate), with the Gumbel noise that run drew passed in:
+    the ids entering the decoder at every step and the final ids must be identical."""
+    import json
+    import os
+
+    from amk.models.muse import BidirectionalDecoder, parallel_decode
+    from util import GOLDEN, load_golden, weights_of
+
+    fx = load_golden("muse_generate_small")
+    meta = json.load(open(os.path.join(GOLDEN, "golden_meta.json")))["muse_generate_small"]
+    cfg = meta["cfg"]
+    dec = BidirectionalDecoder(**cfg).to(device).eval()
+    dec.load_state_dict({k: v.to(device) for k, v in weights_of(fx).items()}, strict=True)
+    trace = []
+    ids = parallel_decode(dec, torch.from_numpy(fx["context"]).to(device), cfg["codebook_size"], cfg["num_patches"],
+                          meta["timesteps"], fused_sampling=fused, gumbel=torch.from_numpy(fx["gumbel"]).to(device), trace=trace)
+    for t, got in enumerate(trace):
+        assert torch.equal(got.cpu(), torch.from_numpy(fx["ids_in"][t])), f"decoder input at step {t}"
+    assert torch.equal(ids.cpu(), torch.from_numpy(fx["final_ids"]))
