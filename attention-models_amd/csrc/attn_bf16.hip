@@ -1,0 +1,531 @@
+// Softmax attention on bf16 operands for the mixed-precision mode (SURVEY.md section 8a2 under the reference's shipped
+// training precision: cfg/vitvqgan.yaml:73 trains under accelerate's bf16 autocast; trainers/vitgqgan.py:149,170).
+// Under autocast the reference's q / kv projections and both einsums of models/softmax_attention.py:62-76 run in
+// bf16 and the softmax in f32; here q, k, v, o (and dO, dq, dk, dv) are bf16 tensors, the two contractions run on
+// v_mfma_f32_32x32x16_bf16 with f32 accumulators, scores / softmax / statistics stay f32 (the reference rounds the
+// scores to bf16 before its softmax; this kernel does not).  Head dim 64, no masks: masked calls, other head dims and
+// f32 tensors take the exact-f32 kernels.
+//
+// Forward: the structure of attn_fwd.hip -- 4 waves x 32 queries, query on the lane, S^T = K Q^T, the S^T
+// accumulators packed to bf16 are the B operand of O^T += V^T P^T -- with
+//   K tile [64 keys][64 d] bf16 in LDS, row stride 144 B: A fragments are 16-byte row reads (conflict-free);
+//   V tile [64 keys][64 d] bf16 in LDS AS STORED, row stride 192 B: the A fragments of V^T (8 keys of one head
+//   dim, in the key order of a packed accumulator) come from ds_read_b64_tr_b16, the hardware transposing read
+//   (4 rows x 16 columns per 16 lanes; 4 rows x 64 B per half-wave land on 64 distinct banks at this stride).
+// Backward: one pass with the key on the lane (as attn_bwd_fused.hip): a workgroup = 8 waves x 32 keys; K and V
+// fragments of the wave's keys in registers, dK^T / dV^T in accumulators; per 32-query tile S = Q K^T and
+// dP = dO V^T (A = rows of Q / dO from LDS), P and dS in registers, dV^T += dO^T P and dK^T += Q^T dS with the
+// packed accumulators as B operands and transposing reads of the dO / Q tiles as A operands; dS crosses LDS once
+// ([key][query] image) and dQ(32 x 64) = dS K over the workgroup's 256 keys runs on v_mfma_f32_16x16x32_bf16, one
+// 16x16 output tile per wave.  dQ leaves as per-key-block f32 partials (plain stores) that a second launch sums in
+// key-block order and rounds to bf16: no atomics, bitwise reproducible.
+#include "attn_common.h"
+
+namespace amk_attn_bf16 {
+
+using amk_attn::Strides;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+constexpr int KSTR = 72;   // bf16 per row of a row-read image (64 + 8): 144 B
+constexpr int TSTR = 96;   // bf16 per row of a transposed-read image (64 + 32): 192 B
+
+struct Params {
+  const __bf16 *q, *k, *v, *o, *d_o;
+  __bf16 *out, *dq, *dk, *dv;
+  float* stats;        // (B, H, I, 2): row max in the log2 domain, row sum
+  float* delta;        // (B, H, I): rowsum(dO * O)
+  float* dq_part;      // (nkblk, B, I, H, 64) f32
+  int B, H, I, J;
+  Strides qs, ks, vs, os, dos, dqs, dks, dvs;
+  float scale;
+  float pinf;
+  int nqblk, nkblk;
+};
+
+__device__ __forceinline__ f32x16 mfmab(bf16x8 a, bf16x8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ float vmax(float a, float b, float pinf) { return __builtin_amdgcn_fmed3f(a, b, pinf); }
+
+// transposing read: this lane's 4 elements = one column of a 4-row x 16-column block of 16-bit values
+__device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(bf16x4, v);
+}
+__device__ __forceinline__ bf16x8 cat4(bf16x4 a, bf16x4 b) {
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = a[i]; r[4 + i] = b[i]; }
+  return r;
+}
+// registers 8t .. 8t+7 of a 32x32 accumulator as the 8 bf16 of a k-slot (the B operand of a product that sums over
+// the accumulator's rows)
+__device__ __forceinline__ bf16x8 pack8(const f32x16& s, int t) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = (__bf16)s[8 * t + j];
+  return r;
+}
+// A fragment of X^T for a product that sums over the ROWS of the LDS tile X [row][col], rows in packed-accumulator
+// order: lane (col = c0 + (l & 31), half) gets rows 16 t + 4 half + (0..3) and + 8.
+//   img: tile base; stride in elements; c0: first column of the 32-column block
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* img, int stride, int t, int c0, int lane) {
+  const int hf = lane >> 5, grp = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  const __bf16* a = img + (16 * t + 4 * hf + q) * stride + c0 + 16 * grp + 4 * pp;
+  return cat4(tr_read(a), tr_read(a + 8 * stride));
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int DUMMY>
+__global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
+  __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * KSTR];
+  __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * TSTR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int qb = wg % p.nqblk, bh = wg / p.nqblk;
+  const int h = bh % p.H, b = bh / p.H;
+  const int qi = qb * 128 + wave * 32 + ln;
+  const bool qvalid = qi < p.I;
+
+  // Q^T operand: lane (query, half) holds q[query][16 c + 8 half + j], j = 0..7, for the four k-blocks c
+  bf16x8 qf[4];
+  {
+    const __bf16* qp = p.q + (int64_t)b * p.qs.sb + (int64_t)qi * p.qs.st + (int64_t)h * p.qs.sh + 8 * hf;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (qvalid) qf[c] = *reinterpret_cast<const bf16x8*>(qp + 16 * c);
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qf[c][j] = (__bf16)0.f;
+      }
+    }
+  }
+  // staging: a 64-row tile of 128-byte rows = 512 pieces of 16 B: two per thread for K, two for V
+  const __bf16* kbase = p.k + (int64_t)b * p.ks.sb + (int64_t)h * p.ks.sh;
+  const __bf16* vbase = p.v + (int64_t)b * p.vs.sb + (int64_t)h * p.vs.sh;
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)(((int64_t)(p.J - 1) * p.ks.st + 64) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vbase, 0, (int)(((int64_t)(p.J - 1) * p.vs.st + 64) * 2), 0x00020000);
+  const int srow = tid >> 3, sch = (tid & 7) * 8;   // rows srow and srow + 32, 8 bf16 at column sch
+  int koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    koff[i] = (int)(((int64_t)(srow + 32 * i) * p.ks.st + sch) * 2);
+    voff[i] = (int)(((int64_t)(srow + 32 * i) * p.vs.st + sch) * 2);
+  }
+  const int kstep = (int)(64 * p.ks.st * 2), vstep = (int)(64 * p.vs.st * 2);
+  float4 kst[2], vst[2];
+  auto prefetch = [&](int t) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      kst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, koff[i] + t * kstep, 0, 0));
+      vst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff[i] + t * vstep, 0, 0));
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<float4*>(&Ks[(srow + 32 * i) * KSTR + sch]) = kst[i];
+      *reinterpret_cast<float4*>(&Vs[(srow + 32 * i) * TSTR + sch]) = vst[i];
+    }
+  };
+  const float c2 = p.scale * AMK_LOG2E;
+  f32x16 o0 = zero16(), o1 = zero16();
+  float m_run = -INFINITY, l_run = 0.f;   // m_run: running max of the RAW scores
+  const int ntile = (p.J + 63) / 64;
+  prefetch(0);
+  for (int t = 0; t < ntile; ++t) {
+    const int j0 = t * 64;
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (t + 1 < ntile) prefetch(t + 1);
+    // ---- S^T = K Q^T: two 32-key blocks x four 16-deep steps
+    f32x16 s0 = zero16(), s1 = zero16();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8 ka = *reinterpret_cast<const bf16x8*>(&Ks[ln * KSTR + 16 * c + 8 * hf]);
+      const bf16x8 kb = *reinterpret_cast<const bf16x8*>(&Ks[(32 + ln) * KSTR + 16 * c + 8 * hf]);
+      s0 = mfmab(ka, qf[c], s0);
+      s1 = mfmab(kb, qf[c], s1);
+    }
+    // keys beyond the sequence (the last tile only): weight 0
+    if (j0 + 64 > p.J) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ja = j0 + acc_row(r, hf);
+        if (ja >= p.J) s0[r] = -INFINITY;
+        if (ja + 32 >= p.J) s1[r] = -INFINITY;
+      }
+    }
+    float mx = vmax(s0[0], s1[0], p.pinf);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = vmax(mx, vmax(s0[r], s1[r], p.pinf), p.pinf);
+    mx = vmax(mx, __shfl_xor(mx, 32, 64), p.pinf);
+    const float m_new = vmax(m_run, mx, p.pinf);
+    const float mc = m_new * c2;
+    float lsum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -mc));
+      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -mc));
+      s0[r] = p0;
+      s1[r] = p1;
+      lsum += p0 + p1;
+    }
+    if (__any(m_new != m_run)) {
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+      l_run *= alpha;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      m_run = m_new;
+    }
+    l_run += lsum;
+    // ---- O^T += V^T P^T: four 16-key slots x two 32-dim blocks
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const bf16x8 pp = (g < 2) ? pack8(s0, g & 1) : pack8(s1, g & 1);
+      const __bf16* vt = Vs + (32 * (g >> 1)) * TSTR;     // the 32-key block of this slot
+      const bf16x8 va = tr_frag(vt, TSTR, g & 1, 0, lane);
+      const bf16x8 vb = tr_frag(vt, TSTR, g & 1, 32, lane);
+      o0 = mfmab(va, pp, o0);
+      o1 = mfmab(vb, pp, o1);
+    }
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (qvalid) {
+    __bf16* op = p.out + (int64_t)b * p.os.sb + (int64_t)qi * p.os.st + (int64_t)h * p.os.sh + 4 * hf;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a, c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { a[e] = (__bf16)(o0[4 * g + e] * inv); c[e] = (__bf16)(o1[4 * g + e] * inv); }
+      *reinterpret_cast<bf16x4*>(op + 8 * g) = a;
+      *reinterpret_cast<bf16x4*>(op + 32 + 8 * g) = c;
+    }
+    if (hf == 0) {
+      float* sp = p.stats + (((int64_t)b * p.H + h) * p.I + qi) * 2;
+      sp[0] = m_run * c2;   // log2 domain, as the f32 kernels store it
+      sp[1] = l_tot;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// delta[b, h, i] = sum_d dO[b, i, h, d] * O[b, i, h, d]   (one wave per 4 rows: 16 lanes x 4 elements per row)
+__global__ __launch_bounds__(256) void attn_bf16_delta_kernel(Params p) {
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);   // over B * H * I
+  const int part = threadIdx.x & 15;
+  if (row >= (int64_t)p.B * p.H * p.I) return;
+  const int i = (int)(row % p.I);
+  const int64_t bh = row / p.I;
+  const int h = (int)(bh % p.H), b = (int)(bh / p.H);
+  const bf16x4 a = *reinterpret_cast<const bf16x4*>(p.d_o + (int64_t)b * p.dos.sb + (int64_t)i * p.dos.st + (int64_t)h * p.dos.sh + 4 * part);
+  const bf16x4 c = *reinterpret_cast<const bf16x4*>(p.o + (int64_t)b * p.os.sb + (int64_t)i * p.os.st + (int64_t)h * p.os.sh + 4 * part);
+  float s = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) s += (float)a[e] * (float)c[e];
+#pragma unroll
+  for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (part == 0) p.delta[row] = s;
+}
+
+constexpr int BW = 8;            // waves per backward workgroup
+constexpr int BKEYS = 32 * BW;   // keys per workgroup
+constexpr int DSTR = 48;         // bf16 per row of the dS^T image [key][32 queries]
+
+__device__ __forceinline__ f32x4v mfma16(bf16x8 a, bf16x8 b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// 16x16x32 operand out of an LDS tile X [row][col] by transposing reads, for a product that sums over X's ROWS in
+// natural order: lane (col = c0 + (l & 15), kq = l >> 4) gets rows r0 + 8 kq + (0..7)
+__device__ __forceinline__ bf16x8 tr_frag16(const __bf16* img, int stride, int r0, int c0, int lane) {
+  const int kq = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const __bf16* a = img + (r0 + 8 * kq + q) * stride + c0 + 4 * pp;
+  return cat4(tr_read(a), tr_read(a + 4 * stride));
+}
+
+__global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  __bf16* Kt = reinterpret_cast<__bf16*>(smem_raw);                 // [256 keys][TSTR]
+  __bf16* dSs = Kt + BKEYS * TSTR;                                  // [256 keys][DSTR]
+  __bf16* tiles = dSs + BKEYS * DSTR;                               // 2 stages x {Qrow, Qtr, dOrow, dOtr}
+  constexpr int STG = 2 * (32 * KSTR + 32 * TSTR);
+  float* stat = reinterpret_cast<float*>(tiles + 2 * STG);          // 2 stages x {m, 1/l, delta} x 32
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int kb = wg % p.nkblk, bh = wg / p.nkblk;
+  const int h = bh % p.H, b = bh / p.H;
+  const int key0 = kb * BKEYS;
+  const int key = key0 + 32 * wave + ln;
+  const bool kvalid = key < p.J;
+  const __bf16* kbase = p.k + (int64_t)b * p.ks.sb + (int64_t)h * p.ks.sh;
+  const __bf16* vbase = p.v + (int64_t)b * p.vs.sb + (int64_t)h * p.vs.sh;
+  // this lane's key: K and V fragments for S = Q K^T and dP = dO V^T (B operands: k = head dim, column = key)
+  bf16x8 kf[4], vf[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    if (kvalid) {
+      kf[c] = *reinterpret_cast<const bf16x8*>(kbase + (int64_t)key * p.ks.st + 16 * c + 8 * hf);
+      vf[c] = *reinterpret_cast<const bf16x8*>(vbase + (int64_t)key * p.vs.st + 16 * c + 8 * hf);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { kf[c][j] = (__bf16)0.f; vf[c][j] = (__bf16)0.f; }
+    }
+  }
+  // the workgroup's K rows as an LDS image for dQ = dS K (rows past the sequence: zeros)
+  {
+    const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kbase, 0, (int)(((int64_t)(p.J - 1) * p.ks.st + 64) * 2), 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = (tid >> 3) + 64 * i, ch = (tid & 7) * 8;
+      const float4 v = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, (int)(((int64_t)(key0 + row) * p.ks.st + ch) * 2), 0, 0));
+      *reinterpret_cast<float4*>(&Kt[row * TSTR + ch]) = v;
+    }
+  }
+  // query-tile staging: threads 0..255 one 16-byte piece of Q, threads 256..511 one of dO; threads 0..31 the statistics
+  const bool isq = tid < 256;
+  const int pt = tid & 255, prow = pt >> 3, pch = (pt & 7) * 8;
+  const __bf16* qbase = p.q + (int64_t)b * p.qs.sb + (int64_t)h * p.qs.sh;
+  const __bf16* dobase = p.d_o + (int64_t)b * p.dos.sb + (int64_t)h * p.dos.sh;
+  const __amdgpu_buffer_rsrc_t t_rsrc = isq
+      ? __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, (int)(((int64_t)(p.I - 1) * p.qs.st + 64) * 2), 0x00020000)
+      : __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, (int)(((int64_t)(p.I - 1) * p.dos.st + 64) * 2), 0x00020000);
+  const int64_t tst = isq ? p.qs.st : p.dos.st;
+  const int toff = (int)(((int64_t)prow * tst + pch) * 2), tstep = (int)(32 * tst * 2);
+  const float* stp = p.stats + ((int64_t)bh * p.I) * 2;
+  const float* dlp = p.delta + (int64_t)bh * p.I;
+  float4 piece;
+  float st_m = 0.f, st_li = 0.f, st_d = 0.f;
+  const int ntile = (p.I + 31) / 32;
+  auto prefetch = [&](int t) {
+    piece = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(t_rsrc, toff + t * tstep, 0, 0));
+    if (tid < 32) {
+      const int i = t * 32 + tid;
+      st_m = 0.f; st_li = 0.f; st_d = 0.f;
+      if (i < p.I) { st_m = stp[2 * i]; st_li = 1.f / stp[2 * i + 1]; st_d = dlp[i]; }
+    }
+  };
+  auto commit = [&](int stage) {
+    __bf16* base = tiles + stage * STG + (isq ? 0 : 32 * KSTR + 32 * TSTR);
+    *reinterpret_cast<float4*>(&base[prow * KSTR + pch]) = piece;                  // row-read image
+    *reinterpret_cast<float4*>(&base[32 * KSTR + prow * TSTR + pch]) = piece;      // transposed-read image
+    if (tid < 32) {
+      float* sb = stat + stage * 96;
+      sb[tid] = st_m; sb[32 + tid] = st_li; sb[64 + tid] = st_d;
+    }
+  };
+  const float c2 = p.scale * AMK_LOG2E;
+  f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+  const bool tail_keys = key0 + BKEYS > p.J;   // some of the workgroup's keys are past the sequence
+  prefetch(0);
+  commit(0);
+  if (ntile > 1) prefetch(1);
+  __syncthreads();
+  float* dqp = p.dq_part + (((int64_t)kb * p.B + b) * p.I * p.H + h) * 64;   // [kb][b][i][h][d]
+  for (int t = 0; t < ntile; ++t) {
+    const int sg = t & 1;
+    const __bf16* Qrow = tiles + sg * STG;
+    const __bf16* Qtr = Qrow + 32 * KSTR;
+    const __bf16* dOrow = Qtr + 32 * TSTR;
+    const __bf16* dOtr = dOrow + 32 * KSTR;
+    const float* sb = stat + sg * 96;
+    // ---- S = Q K^T, dP = dO V^T: rows = queries, columns = keys (this lane's key)
+    f32x16 s = zero16(), dp = zero16();
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qrow[ln * KSTR + 16 * c + 8 * hf]);
+      const bf16x8 da = *reinterpret_cast<const bf16x8*>(&dOrow[ln * KSTR + 16 * c + 8 * hf]);
+      s = mfmab(qa, kf[c], s);
+      dp = mfmab(da, vf[c], dp);
+    }
+    // ---- P and dS (registers r <-> query rows 8 g + 4 half + e of the tile)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 m4 = *reinterpret_cast<const float4*>(&sb[8 * g + 4 * hf]);
+      const float4 l4 = *reinterpret_cast<const float4*>(&sb[32 + 8 * g + 4 * hf]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&sb[64 + 8 * g + 4 * hf]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int r = 4 * g + e;
+        const float mm = e == 0 ? m4.x : (e == 1 ? m4.y : (e == 2 ? m4.z : m4.w));
+        const float li = e == 0 ? l4.x : (e == 1 ? l4.y : (e == 2 ? l4.z : l4.w));
+        const float dl = e == 0 ? d4.x : (e == 1 ? d4.y : (e == 2 ? d4.z : d4.w));
+        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -mm)) * li;
+        if (tail_keys) pr = kvalid ? pr : 0.f;
+        s[r] = pr;
+        dp[r] = pr * (dp[r] - dl) * p.scale;
+      }
+    }
+    // ---- dS^T image for dQ: this lane's key row, its 16 queries as four 8-byte pieces
+    {
+      __bf16* row = dSs + (32 * wave + ln) * DSTR + 4 * hf;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        bf16x4 w;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[e] = (__bf16)dp[4 * g + e];
+        *reinterpret_cast<bf16x4*>(row + 8 * g) = w;
+      }
+    }
+    // ---- dV^T += dO^T P, dK^T += Q^T dS (sums over the tile's 32 queries: two 16-deep slots)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const bf16x8 pb = pack8(s, u), db = pack8(dp, u);
+      dv0 = mfmab(tr_frag(dOtr, TSTR, u, 0, lane), pb, dv0);
+      dv1 = mfmab(tr_frag(dOtr, TSTR, u, 32, lane), pb, dv1);
+      dk0 = mfmab(tr_frag(Qtr, TSTR, u, 0, lane), db, dk0);
+      dk1 = mfmab(tr_frag(Qtr, TSTR, u, 32, lane), db, dk1);
+    }
+    __syncthreads();   // every wave's dS rows are in LDS
+    // ---- dQ tile (32 queries x 64 dims) = dS (32 x 256 keys) K (256 x 64): wave w owns the 16 x 16 block (w & 1, w >> 1)
+    {
+      const int qblk = wave & 1, dblk = wave >> 1;
+      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < BKEYS / 32; ++ks) {
+        const bf16x8 a = tr_frag16(dSs, DSTR, 32 * ks, 16 * qblk, lane);
+        const bf16x8 bb = tr_frag16(Kt, TSTR, 32 * ks, 16 * dblk, lane);
+        acc = mfma16(a, bb, acc);
+      }
+      const int i0 = t * 32 + 16 * qblk + 4 * (lane >> 4);
+      float* o = dqp + (int64_t)i0 * p.H * 64 + 16 * dblk + (lane & 15);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (i0 + r < p.I) o[(int64_t)r * p.H * 64] = acc[r];
+    }
+    if (t + 1 < ntile) commit((t + 1) & 1);
+    if (t + 2 < ntile) prefetch(t + 2);
+    __syncthreads();   // dS reads done; the next tile's images and statistics are in place
+  }
+  if (kvalid) {
+    __bf16* kp = p.dk + (int64_t)b * p.dks.sb + (int64_t)key * p.dks.st + (int64_t)h * p.dks.sh + 4 * hf;
+    __bf16* vp = p.dv + (int64_t)b * p.dvs.sb + (int64_t)key * p.dvs.st + (int64_t)h * p.dvs.sh + 4 * hf;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      bf16x4 a, c, d, e4;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        a[e] = (__bf16)dk0[4 * g + e]; c[e] = (__bf16)dk1[4 * g + e];
+        d[e] = (__bf16)dv0[4 * g + e]; e4[e] = (__bf16)dv1[4 * g + e];
+      }
+      *reinterpret_cast<bf16x4*>(kp + 8 * g) = a;
+      *reinterpret_cast<bf16x4*>(kp + 32 + 8 * g) = c;
+      *reinterpret_cast<bf16x4*>(vp + 8 * g) = d;
+      *reinterpret_cast<bf16x4*>(vp + 32 + 8 * g) = e4;
+    }
+  }
+}
+
+// dq[b, i, h, :] = sum over key blocks (in order) of the f32 partials, rounded to bf16 once
+__global__ __launch_bounds__(256) void attn_bf16_dq_reduce_kernel(Params p) {
+  const int64_t n4 = (int64_t)p.B * p.I * p.H * 16;   // float4 pieces of one partial
+  const int64_t i4 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i4 >= n4) return;
+  const float4* src = reinterpret_cast<const float4*>(p.dq_part) + i4;
+  float4 s = src[0];
+  for (int kb = 1; kb < p.nkblk; ++kb) {
+    const float4 v = src[kb * n4];
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  const int d4 = (int)(i4 & 15);
+  const int64_t r = i4 >> 4;            // (b, i, h)
+  const int h = (int)(r % p.H);
+  const int64_t bi = r / p.H;
+  const int i = (int)(bi % p.I), b = (int)(bi / p.I);
+  bf16x4 w;
+  w[0] = (__bf16)s.x; w[1] = (__bf16)s.y; w[2] = (__bf16)s.z; w[3] = (__bf16)s.w;
+  *reinterpret_cast<bf16x4*>(p.dq + (int64_t)b * p.dqs.sb + (int64_t)i * p.dqs.st + (int64_t)h * p.dqs.sh + 4 * d4) = w;
+}
+
+}  // namespace amk_attn_bf16
+
+using namespace amk_attn_bf16;
+
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static bool st_ok(const Strides& s) { return s.sb % 8 == 0 && s.st % 8 == 0 && s.sh % 8 == 0; }
+
+extern "C" int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, float* stats,
+                                 int B, int H, int I, int J, int Dh,
+                                 int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                                 int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
+                                 float scale, void* stream) {
+  AMK_CHECK_ARG(q && k && v && o && stats, "amk_attn_bf16_fwd: null tensor pointer");
+  AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_bf16_fwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
+  AMK_CHECK_SUPPORTED(Dh == 64, "amk_attn_bf16_fwd: head dim %d not supported (64)", Dh);
+  Params p = {};
+  p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.out = (__bf16*)o; p.stats = stats;
+  p.B = B; p.H = H; p.I = I; p.J = J;
+  p.qs = {q_sb, q_st, q_sh}; p.ks = {k_sb, k_st, k_sh}; p.vs = {v_sb, v_st, v_sh}; p.os = {o_sb, o_st, o_sh};
+  p.scale = scale; p.pinf = INFINITY;
+  p.nqblk = (I + 127) / 128;
+  AMK_CHECK_ARG(al16(q) && al16(k) && al16(v) && al16(o) && st_ok(p.qs) && st_ok(p.ks) && st_ok(p.vs) && st_ok(p.os),
+                "amk_attn_bf16_fwd: pointers must be 16-byte aligned and strides multiples of 8 elements");
+  const int64_t nwg = (int64_t)B * H * p.nqblk;
+  AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_bf16_fwd: grid too large");
+  AMK_CHECK_SUPPORTED(((int64_t)J + 64) * k_st * 2 < (1ll << 31) && ((int64_t)J + 64) * v_st * 2 < (1ll << 31),
+                      "amk_attn_bf16_fwd: one (batch, head) K/V slab must span < 2 GiB");
+  hipLaunchKernelGGL(attn_bf16_fwd_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  AMK_CHECK_LAUNCH("amk_attn_bf16_fwd");
+  return AMK_OK;
+}
+
+extern "C" int64_t amk_attn_bf16_bwd_ws_floats(int B, int H, int I, int J) {
+  if (B <= 0 || H <= 0 || I <= 0 || J <= 0) return 0;
+  const int64_t nkblk = (J + BKEYS - 1) / BKEYS;
+  return (int64_t)B * H * I + nkblk * B * I * H * 64;
+}
+
+extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const float* stats, const void* d_o,
+                                 void* dq, void* dk, void* dv, float* ws,
+                                 int B, int H, int I, int J, int Dh,
+                                 int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                                 int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
+                                 int64_t do_sb, int64_t do_st, int64_t do_sh, int64_t dq_sb, int64_t dq_st, int64_t dq_sh,
+                                 int64_t dk_sb, int64_t dk_st, int64_t dk_sh, int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
+                                 float scale, void* stream) {
+  AMK_CHECK_ARG(q && k && v && o && stats && d_o && dq && dk && dv && ws, "amk_attn_bf16_bwd: null tensor pointer");
+  AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_bf16_bwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
+  AMK_CHECK_SUPPORTED(Dh == 64, "amk_attn_bf16_bwd: head dim %d not supported (64)", Dh);
+  Params p = {};
+  p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.o = (const __bf16*)o; p.d_o = (const __bf16*)d_o;
+  p.dq = (__bf16*)dq; p.dk = (__bf16*)dk; p.dv = (__bf16*)dv;
+  p.stats = const_cast<float*>(stats);
+  p.B = B; p.H = H; p.I = I; p.J = J;
+  p.qs = {q_sb, q_st, q_sh}; p.ks = {k_sb, k_st, k_sh}; p.vs = {v_sb, v_st, v_sh}; p.os = {o_sb, o_st, o_sh};
+  p.dos = {do_sb, do_st, do_sh}; p.dqs = {dq_sb, dq_st, dq_sh}; p.dks = {dk_sb, dk_st, dk_sh}; p.dvs = {dv_sb, dv_st, dv_sh};
+  p.scale = scale; p.pinf = INFINITY;
+  p.nkblk = (J + BKEYS - 1) / BKEYS;
+  p.delta = ws;
+  p.dq_part = ws + (int64_t)B * H * I;
+  AMK_CHECK_ARG(al16(q) && al16(k) && al16(v) && al16(o) && al16(d_o) && al16(dq) && al16(dk) && al16(dv) && al16(p.dq_part) &&
+                    st_ok(p.qs) && st_ok(p.ks) && st_ok(p.vs) && st_ok(p.os) && st_ok(p.dos) && st_ok(p.dqs) && st_ok(p.dks) && st_ok(p.dvs),
+                "amk_attn_bf16_bwd: pointers must be 16-byte aligned and strides multiples of 8 elements");
+  AMK_CHECK_SUPPORTED(((int64_t)J + BKEYS) * k_st * 2 < (1ll << 31) && ((int64_t)J + BKEYS) * v_st * 2 < (1ll << 31) &&
+                          ((int64_t)I + 32) * q_st * 2 < (1ll << 31) && ((int64_t)I + 32) * do_st * 2 < (1ll << 31),
+                      "amk_attn_bf16_bwd: one (batch, head) slab must span < 2 GiB");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int64_t rows = (int64_t)B * H * I;
+  hipLaunchKernelGGL(attn_bf16_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, p);
+  const int64_t nwg = (int64_t)B * H * p.nkblk;
+  AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_bf16_bwd: grid too large");
+  constexpr size_t lds = (size_t)(BKEYS * TSTR + BKEYS * DSTR + 4 * (32 * KSTR + 32 * TSTR)) * 2 + 2 * 96 * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_bf16_bwd_kernel, dim3((unsigned)nwg), dim3(64 * BW), lds, st, p);
+  const int64_t n4 = (int64_t)B * I * H * 16;
+  hipLaunchKernelGGL(attn_bf16_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p);
+  AMK_CHECK_LAUNCH("amk_attn_bf16_bwd");
+  return AMK_OK;
+}

@@ -476,6 +476,30 @@ int64_t amk_gemm_f32_ws_bytes(const amk_gemm_desc* d);
 int amk_gemm_f32(const amk_gemm_desc* d, void* workspace, int64_t ws_bytes, void* stream);
 int amk_row_stats(const float* x, int64_t M, int D, float eps, float* mean, float* rstd, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Softmax attention on bf16 tensors (the reference's shipped training precision: cfg/vitvqgan.yaml:73 runs
+ * models/softmax_attention.py:62-76 under bf16 autocast -- projections and both einsums in bf16, softmax in f32).
+ * q, k, v, o, d_o, dq, dk, dv are bf16 (2-byte elements, strides in ELEMENTS, multiples of 8, 16-byte aligned);
+ * contractions on v_mfma_f32_32x32x16_bf16 with f32 accumulation; scores, softmax and stats (B,H,I,2) are f32 as in
+ * amk_attn_fwd.  Head dim 64, no masks (masked calls use the f32 entry points).
+ * Backward: ws = amk_attn_bf16_bwd_ws_floats(B,H,I,J) floats (row sums of dO*O and per-key-block dq partials, summed
+ * in key-block order by a second launch: no atomics, bitwise reproducible).
+ * -------------------------------------------------------------------------- */
+int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, float* stats,
+                      int B, int H, int I, int J, int D,
+                      int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                      int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
+                      float scale, void* stream);
+int64_t amk_attn_bf16_bwd_ws_floats(int B, int H, int I, int J);
+int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const float* stats, const void* d_o,
+                      void* dq, void* dk, void* dv, float* ws,
+                      int B, int H, int I, int J, int D,
+                      int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
+                      int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
+                      int64_t do_sb, int64_t do_st, int64_t do_sh, int64_t dq_sb, int64_t dq_st, int64_t dq_sh,
+                      int64_t dk_sb, int64_t dk_st, int64_t dk_sh, int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
+                      float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

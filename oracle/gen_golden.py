@@ -401,6 +401,64 @@ def gen_muse_decoder(mods, meta):
                                       n_params=sum(p.numel() for p in m.parameters()))
 
 
+def gen_softmax_attention_bf16(mods, meta):
+    """The reference's SoftmaxAttention under torch.autocast(bfloat16) -- its shipped training precision
+    (cfg/vitvqgan.yaml:73; trainers/vitgqgan.py:149,170 run the forwards inside accelerator.autocast()): Linear and
+    einsum in bf16, softmax in f32 (autocast's fp32 list), f32 parameters and gradients.  Stored next to the same
+    module's f32 results, so that the fixture itself says what tolerance the mode supports: `err_out` / `err_gx` =
+    max |autocast - f32| / max |f32| of the reference against ITSELF."""
+    SA = mods["softmax_attention"].SoftmaxAttention
+    dim, h, d, B, T, J = 128, 2, 64, 2, 96, 77
+    m = SA(dim, h, d)
+    randomize_(m, 21)
+    x = seeded((B, T, dim), 301)
+    ctx = seeded((B, J, dim), 302)
+    cot = seeded((B, T, dim), 303)
+    keymask = torch.ones(B, T, dtype=torch.bool)
+    keymask[0, -9:] = False
+    ctxmask = torch.ones(B, J, dtype=torch.bool)
+    ctxmask[:, -17:] = False
+    params = [p for _, p in sorted(m.named_parameters())]
+    pnames = [n for n, _ in sorted(m.named_parameters())]
+    arrays = dict(np_state(m), x=x.numpy(), context=ctx.numpy(), cot=cot.numpy(), keymask=keymask.numpy(),
+                  ctxmask=ctxmask.numpy(), dims=np.array([dim, h, d]))
+    variants = {"self": dict(), "self_keymask": dict(context_mask=keymask), "cross_ctxmask": dict(context=ctx, context_mask=ctxmask)}
+    errs = {}
+    for vname, kw in variants.items():
+        res = {}
+        for mode in ("f32", "bf16"):
+            xr = x.clone().requires_grad_(True)
+            kw2 = dict(kw)
+            wrt = [xr]
+            if "context" in kw:
+                kw2["context"] = ctx.clone().requires_grad_(True)
+                wrt.append(kw2["context"])
+            if mode == "bf16":
+                with torch.autocast("cpu", dtype=torch.bfloat16):
+                    out = m(xr, **kw2)
+            else:
+                out = m(xr, **kw2)
+            gs = torch.autograd.grad((out.float() * cot).sum(), wrt + params)
+            res[mode] = (out.detach().float(), [g.detach().float() for g in gs])
+        (o32, g32), (o16, g16) = res["f32"], res["bf16"]
+        arrays[f"{vname}:out"] = o16.numpy()
+        arrays[f"{vname}:out_f32"] = o32.numpy()
+        arrays[f"{vname}:gx"] = g16[0].numpy()
+        arrays[f"{vname}:gx_f32"] = g32[0].numpy()
+        off = 2 if "context" in kw else 1
+        if "context" in kw:
+            arrays[f"{vname}:gctx"] = g16[1].numpy()
+            arrays[f"{vname}:gctx_f32"] = g32[1].numpy()
+        for n, a, b in zip(pnames, g16[off:], g32[off:]):
+            arrays[f"{vname}:g:{n}"] = a.numpy()
+            arrays[f"{vname}:g32:{n}"] = b.numpy()
+        rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+        errs[vname] = dict(err_out=rel(o16, o32), err_gx=rel(g16[0], g32[0]),
+                           err_gparams=max(rel(a, b) for a, b in zip(g16[off:], g32[off:])))
+    meta["softmax_attention_bf16"] = dict(bytes=save("softmax_attention_bf16", **arrays), variants=list(variants),
+                                          reference_autocast_vs_reference_f32=errs)
+
+
 def gen_muse_generate(mods, meta):
     """The parallel decode loop itself: the reference's MUSE.generate (models/muse.py:180-239) called as an unbound
     function on a namespace holding the reference's BidirectionalDecoder, a synthetic-context text encoder (SURVEY.md
@@ -462,6 +520,7 @@ def main():
     gen_vit_moe(mods, meta)
     gen_muse_decoder(mods, meta)
     gen_muse_generate(mods, meta)
+    gen_softmax_attention_bf16(mods, meta)
     with open(os.path.join(OUT, "golden_meta.json"), "w") as f:
         json.dump(meta, f, indent=1, sort_keys=True)
     total = sum(v["bytes"] for v in meta.values() if isinstance(v, dict) and "bytes" in v)
