@@ -255,8 +255,8 @@ __device__ __forceinline__ bf16x8 tr_frag16(const __bf16* img, int stride, int r
 __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* Kt = reinterpret_cast<__bf16*>(smem_raw);                 // [256 keys][TSTR]
-  __bf16* dSs = Kt + BKEYS * TSTR;                                  // [256 keys][DSTR]
-  __bf16* tiles = dSs + BKEYS * DSTR;                               // 2 stages x {Qrow, Qtr, dOrow, dOtr}
+  __bf16* dSs = Kt + BKEYS * TSTR;                                  // 2 x [256 keys][DSTR]
+  __bf16* tiles = dSs + 2 * BKEYS * DSTR;                           // 2 stages x {Qrow, Qtr, dOrow, dOtr}
   constexpr int STG = 2 * (32 * KSTR + 32 * TSTR);
   float* stat = reinterpret_cast<float*>(tiles + 2 * STG);          // 2 stages x {m, 1/l, delta} x 32
 
@@ -292,14 +292,11 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
     }
   }
   // query-tile staging: threads 0..255 one 16-byte piece of Q, threads 256..511 one of dO; threads 0..31 the statistics
-  const bool isq = tid < 256;
+  const bool isq = wave < 4;   // (wave-uniform: a descriptor chosen per lane would be loaded through a waterfall loop)
   const int pt = tid & 255, prow = pt >> 3, pch = (pt & 7) * 8;
-  const __bf16* qbase = p.q + (int64_t)b * p.qs.sb + (int64_t)h * p.qs.sh;
-  const __bf16* dobase = p.d_o + (int64_t)b * p.dos.sb + (int64_t)h * p.dos.sh;
-  const __amdgpu_buffer_rsrc_t t_rsrc = isq
-      ? __builtin_amdgcn_make_buffer_rsrc((void*)qbase, 0, (int)(((int64_t)(p.I - 1) * p.qs.st + 64) * 2), 0x00020000)
-      : __builtin_amdgcn_make_buffer_rsrc((void*)dobase, 0, (int)(((int64_t)(p.I - 1) * p.dos.st + 64) * 2), 0x00020000);
+  const __bf16* tbase = isq ? p.q + (int64_t)b * p.qs.sb + (int64_t)h * p.qs.sh : p.d_o + (int64_t)b * p.dos.sb + (int64_t)h * p.dos.sh;
   const int64_t tst = isq ? p.qs.st : p.dos.st;
+  const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tbase, 0, (int)(((int64_t)(p.I - 1) * tst + 64) * 2), 0x00020000);
   const int toff = (int)(((int64_t)prow * tst + pch) * 2), tstep = (int)(32 * tst * 2);
   const float* stp = p.stats + ((int64_t)bh * p.I) * 2;
   const float* dlp = p.delta + (int64_t)bh * p.I;
@@ -331,6 +328,22 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   if (ntile > 1) prefetch(1);
   __syncthreads();
   float* dqp = p.dq_part + (((int64_t)kb * p.B + b) * p.I * p.H + h) * 64;   // [kb][b][i][h][d]
+  auto dq_tile = [&](int tt) {
+    const __bf16* img = dSs + (tt & 1) * BKEYS * DSTR;
+    const int qblk = wave & 1, dblk = wave >> 1;
+    f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < BKEYS / 32; ++ks) {
+      const bf16x8 a = tr_frag16(img, DSTR, 32 * ks, 16 * qblk, lane);
+      const bf16x8 bb = tr_frag16(Kt, TSTR, 32 * ks, 16 * dblk, lane);
+      acc = mfma16(a, bb, acc);
+    }
+    const int i0 = tt * 32 + 16 * qblk + 4 * (lane >> 4);
+    float* o = dqp + (int64_t)i0 * p.H * 64 + 16 * dblk + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (i0 + r < p.I) o[(int64_t)r * p.H * 64] = acc[r];
+  };
   for (int t = 0; t < ntile; ++t) {
     const int sg = t & 1;
     const __bf16* Qrow = tiles + sg * STG;
@@ -365,9 +378,10 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
         dp[r] = pr * (dp[r] - dl) * p.scale;
       }
     }
-    // ---- dS^T image for dQ: this lane's key row, its 16 queries as four 8-byte pieces
+    // ---- dS^T image for dQ: this lane's key row, its 16 queries as four 8-byte pieces (image t & 1: the dQ product
+    //      of tile t runs in the NEXT iteration, beside that tile's S / dP work, so one barrier per tile is enough)
     {
-      __bf16* row = dSs + (32 * wave + ln) * DSTR + 4 * hf;
+      __bf16* row = dSs + (t & 1) * BKEYS * DSTR + (32 * wave + ln) * DSTR + 4 * hf;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         bf16x4 w;
@@ -376,6 +390,9 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
         *reinterpret_cast<bf16x4*>(row + 8 * g) = w;
       }
     }
+    // ---- dQ of the previous tile (32 queries x 64 dims) = dS (32 x 256 keys) K (256 x 64): wave w owns the
+    //      16 x 16 block (w & 1, w >> 1)
+    if (t > 0) dq_tile(t - 1);
     // ---- dV^T += dO^T P, dK^T += Q^T dS (sums over the tile's 32 queries: two 16-deep slots)
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -385,27 +402,11 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
       dk0 = mfmab(tr_frag(Qtr, TSTR, u, 0, lane), db, dk0);
       dk1 = mfmab(tr_frag(Qtr, TSTR, u, 32, lane), db, dk1);
     }
-    __syncthreads();   // every wave's dS rows are in LDS
-    // ---- dQ tile (32 queries x 64 dims) = dS (32 x 256 keys) K (256 x 64): wave w owns the 16 x 16 block (w & 1, w >> 1)
-    {
-      const int qblk = wave & 1, dblk = wave >> 1;
-      f32x4v acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < BKEYS / 32; ++ks) {
-        const bf16x8 a = tr_frag16(dSs, DSTR, 32 * ks, 16 * qblk, lane);
-        const bf16x8 bb = tr_frag16(Kt, TSTR, 32 * ks, 16 * dblk, lane);
-        acc = mfma16(a, bb, acc);
-      }
-      const int i0 = t * 32 + 16 * qblk + 4 * (lane >> 4);
-      float* o = dqp + (int64_t)i0 * p.H * 64 + 16 * dblk + (lane & 15);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (i0 + r < p.I) o[(int64_t)r * p.H * 64] = acc[r];
-    }
     if (t + 1 < ntile) commit((t + 1) & 1);
     if (t + 2 < ntile) prefetch(t + 2);
-    __syncthreads();   // dS reads done; the next tile's images and statistics are in place
+    __syncthreads();   // this tile's dS rows are in LDS, the next tile's images and statistics in place
   }
+  dq_tile(ntile - 1);
   if (kvalid) {
     __bf16* kp = p.dk + (int64_t)b * p.dks.sb + (int64_t)key * p.dks.st + (int64_t)h * p.dks.sh + 4 * hf;
     __bf16* vp = p.dv + (int64_t)b * p.dvs.sb + (int64_t)key * p.dvs.st + (int64_t)h * p.dvs.sh + 4 * hf;
@@ -517,10 +518,10 @@ extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, co
   hipLaunchKernelGGL(attn_bf16_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, p);
   const int64_t nwg = (int64_t)B * H * p.nkblk;
   AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_bf16_bwd: grid too large");
-  constexpr size_t lds = (size_t)(BKEYS * TSTR + BKEYS * DSTR + 4 * (32 * KSTR + 32 * TSTR)) * 2 + 2 * 96 * 4;
+  constexpr size_t lds = (size_t)(BKEYS * TSTR + 2 * BKEYS * DSTR + 4 * (32 * KSTR + 32 * TSTR)) * 2 + 2 * 96 * 4;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr_set = true;
   }
   hipLaunchKernelGGL(attn_bf16_bwd_kernel, dim3((unsigned)nwg), dim3(64 * BW), lds, st, p);

@@ -33,6 +33,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md "Peak FP32 (matrix)"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md "Peak BF16/FP16 MFMA", dense
 HBM_PEAK_GBS = 8000.0
 
 VIT = dict(dim=256, img_size=256, patch_size=8, n_heads=8, d_head=64, depth=6, mlp_dim=2048, dropout=0.0)
@@ -153,6 +154,39 @@ def kernel_rooflines(B, dev, iters):
         r["frac_of_f32_mfma_peak"] = r["tflops"] / F32_MFMA_PEAK_TFLOPS
         r["ms_per_step"] = r["avg_ms"] * r["launches_per_step"]
     return out
+
+
+def bf16_attention_block(B, dev, iters):
+    """The bf16-MFMA attention kernels at the workload's layer shape: launch times, algorithmic TFLOP/s against the
+    dense bf16 MFMA peak, and their error against the exact-f32 kernels on the same (bf16-rounded) operands."""
+    from amk import ops
+
+    H, T, D = VIT["n_heads"], (VIT["img_size"] // VIT["patch_size"]) ** 2, VIT["d_head"]
+    g = torch.Generator().manual_seed(77)
+    q2 = torch.randn(B, T, H * D, generator=g).to(dev).bfloat16().requires_grad_(True)
+    kv2 = torch.randn(B, T, 2 * H * D, generator=g).to(dev).bfloat16().requires_grad_(True)
+    cot = torch.randn(B, T, H * D, generator=g).to(dev).bfloat16()
+    f = lambda: ops.attention_fused_kv(q2, kv2, H, D, D ** -0.5)
+    t_f = time_launches(f, iters)
+    t_fb = time_launches(lambda: torch.autograd.grad(f(), [q2, kv2], cot), iters)
+    o16 = f()
+    dq16, dkv16 = torch.autograd.grad(o16, [q2, kv2], cot)
+    qf, kvf = q2.detach().float().requires_grad_(True), kv2.detach().float().requires_grad_(True)
+    o32 = ops.attention_fused_kv(qf, kvf, H, D, D ** -0.5)
+    dq32, dkv32 = torch.autograd.grad(o32, [qf, kvf], cot.float())
+    rel = lambda a, b: float((a.float() - b).abs().max() / b.abs().max())
+    core = 4.0 * B * H * T * T * D
+    t_b = t_fb - t_f
+    return {"roofline_bf16": {
+        "bound": "mfma", "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "kernels": [dict(kernel="attn_bf16_fwd_kernel", avg_launch_ms=t_f * 1e3, achieved=core / t_f / 1e12,
+                         frac=core / t_f / 1e12 / BF16_MFMA_PEAK_TFLOPS, flop_per_launch=core, launches_per_step=4 * VIT["depth"]),
+                    dict(kernel="attn_bf16_bwd (delta + fused + dq reduce)", avg_launch_ms=t_b * 1e3,
+                         achieved=2.5 * core / t_b / 1e12, frac=2.5 * core / t_b / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+                         flop_per_launch=2.5 * core, launches_per_step=2 * VIT["depth"],
+                         note="10*B*h*I*J*d: five products (S recomputed from the statistics)")]},
+        "error_vs_f32_kernels": {"out": rel(o16, o32), "dq": rel(dq16, dq32), "dkv": rel(dkv16, dkv32),
+                                 "what": "max |bf16 - f32| / max |f32| of the attention core on the same bf16-rounded operands"}}
 
 
 def vitmoe_block(dev, batch=64, steps=3):
@@ -387,6 +421,17 @@ def main():
         variants["variant_split_bf16_gemms_and_attention_forward"] = variant(
             both_on, both_off, "the two split-bf16 variants above together; not the headline value")
         note("combined split-bf16 variant done")
+        # the reference's shipped training precision (cfg/vitvqgan.yaml:73: accelerate bf16 autocast): its own line,
+        # its own dtype, its own roofline -- never the headline (the north star's tolerance is an f32 one)
+        v16 = variant(lambda: setattr(trainer, "autocast", torch.bfloat16), lambda: setattr(trainer, "autocast", None),
+                      "both phases' forwards and losses under torch.autocast(bfloat16) as the reference's accelerator.autocast() "
+                      "blocks run them (trainers/vitgqgan.py:149,170): Linear / convolution GEMMs in bf16 (vendor library), "
+                      "attention on the bf16-MFMA kernels of csrc/attn_bf16.hip (bf16 operands, f32 scores / softmax / "
+                      "accumulators), VQ lookup exact f32; parameters, gradients and optimizer state f32; not the headline value")
+        v16["dtype"] = "bf16 (autocast)"
+        v16.update(bf16_attention_block(args.batch, dev, args.kernel_iters))
+        variants["variant_bf16_autocast"] = v16
+        note("bf16-autocast variant done")
 
     kernels = None
     if rank == 0 and not args.no_kernels:
