@@ -963,9 +963,9 @@ class _LinearX6(torch.autograd.Function):
 # its epilogue, the weight gradient with the bias gradient (column sums of dY) inside the same product, q and kv
 # projections as one launch, the SwiGLU gate of the FFN in the w12 GEMM's epilogue and its derivative in the epilogue
 # of the w3 input gradient.  DENSE_MODE (AMK_DENSE): "amk" = every product on amk_gemm_f32; "auto" (default) = the
-# plain input gradient dY W stays with the vendor library where that is the faster kernel (measured,
-# tools/kbench_dense.py: 0.88-0.96x), everything else on amk_gemm_f32; "lib" = the round-2 path (library GEMMs +
-# amk_colsum / amk_swiglu launches).
+# plain input gradient dY W and forwards with fewer than 512 output columns stay with the vendor library where that is
+# the faster kernel (measured, tools/kbench_dense.py: 0.80-0.96x), everything else on amk_gemm_f32; "lib" = the
+# round-2 path (library GEMMs + amk_colsum / amk_swiglu launches).
 DENSE_MODE = os.environ.get("AMK_DENSE", "auto")
 
 
@@ -997,6 +997,10 @@ class _DenseLinear(torch.autograd.Function):
         ctx.save_for_backward(x2, weight)
         ctx.x_shape = x.shape
         ctx.has_bias = bias is not None
+        if DENSE_MODE == "auto" and weight.shape[0] < 512:
+            # outputs of one or two column tiles (W_o, w3, patch / quant layers: one tile per workgroup, nothing for the
+            # persistent walk to overlap): the library's kernel is 5-10 % faster there (tools/kbench_dense.py)
+            return torch.nn.functional.linear(x, weight, bias)
         return dense.gemm_nt(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
