@@ -79,6 +79,10 @@ SIGNATURES = {
     "amk_attn_bf16_fwd": (_I, [_P] * 5 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_attn_bf16_bwd_ws_floats": (_L, [_I, _I, _I, _I]),
     "amk_attn_bf16_bwd": (_I, [_P] * 10 + [_I] * 5 + [_L] * 24 + [_F, _P]),
+    "amk_swiglu_bf16_fwd": (_I, [_P, _L, _I, _P, _P]),
+    "amk_swiglu_bf16_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
+    "amk_add_layernorm_mixed_fwd": (_I, [_P, _I, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
+    "amk_add_layernorm_mixed_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "amk_sample_step": (_I, [_P, _P, _F, _P, _c.c_uint64, _c.c_uint64, _F, _L, _I, _I, _P, _F, _P, _P, _P]),
     "amk_moe_route_ws_ints": (_L, [_L, _I, _I]),
     "amk_moe_route": (_I, [_P, _L, _I, _I] + [_P] * 8),

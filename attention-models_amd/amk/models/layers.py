@@ -15,15 +15,16 @@ class Linear(nn.Linear):
 
 class LayerNorm(nn.LayerNorm):
     """nn.LayerNorm over the last axis.  ``forward(x)`` = LN(x); ``forward(x, residual)`` returns
-    ``(x + residual, LN(x + residual))`` from one kernel."""
+    ``(x + residual, LN(x + residual))`` from one kernel.  ``branch=True``: the normalised output only feeds Linear
+    layers (the pre-LN blocks) -- under bf16 autocast it is then written in bf16 by the same kernel."""
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, branch=False):
         fusable = x.is_cuda and self.elementwise_affine and self.bias is not None and len(self.normalized_shape) == 1
         if residual is None:
             if not fusable:
                 return F.layer_norm(x, self.normalized_shape, self.weight, self.bias, self.eps)
-            return ops.layer_norm(x, self.weight, self.bias, self.eps)
+            return ops.layer_norm(x, self.weight, self.bias, self.eps, branch=branch)
         if not fusable:
             h = x + residual
             return h, F.layer_norm(h, self.normalized_shape, self.weight, self.bias, self.eps)
-        return ops.add_layer_norm(x, residual, self.weight, self.bias, self.eps)
+        return ops.add_layer_norm(x, residual, self.weight, self.bias, self.eps, branch=branch)

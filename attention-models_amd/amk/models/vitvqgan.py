@@ -64,10 +64,10 @@ class EncoderLayer(nn.Module):
         and each add is done inside the LayerNorm kernel that consumes it (amk_add_layernorm_fwd).
         Returns the new (h, pending)."""
         if pending is None:
-            y = self.norm1(h)
+            y = self.norm1(h, branch=True)
         else:
-            h, y = self.norm1(h, pending)
-        h, y = self.norm2(h, self.self_attn(y))
+            h, y = self.norm1(pending, h, branch=True)
+        h, y = self.norm2(self.self_attn(y), h, branch=True)
         return h, self.feed_forward(y)
 
 

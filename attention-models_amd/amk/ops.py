@@ -759,8 +759,40 @@ def _f32_outside_autocast(fn, x):
     return fn(x)
 
 
+class _SwiGLUBF16(torch.autograd.Function):
+    """The gate on bf16 tensors (mixed precision): bf16 in, bf16 out, f32 arithmetic (csrc/mixed_bf16.hip)."""
+
+    @staticmethod
+    def forward(ctx, ab):
+        H = ab.shape[-1] // 2
+        ab2 = ab.contiguous().view(-1, 2 * H)
+        M = ab2.shape[0]
+        out = torch.empty((M, H), device=ab.device, dtype=torch.bfloat16)
+        _lib.check(_lib.load().amk_swiglu_bf16_fwd(_ptr(ab2), M, H, _ptr(out), _stream()), "amk_swiglu_bf16_fwd")
+        ctx.save_for_backward(ab2)
+        ctx.shape = ab.shape
+        return out.view(*ab.shape[:-1], H)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        (ab2,) = ctx.saved_tensors
+        M, H2 = ab2.shape
+        d_out = d_out.to(torch.bfloat16).contiguous().view(M, H2 // 2)
+        d_ab = torch.empty_like(ab2)
+        _lib.check(_lib.load().amk_swiglu_bf16_bwd(_ptr(ab2), _ptr(d_out), M, H2 // 2, _ptr(d_ab), _stream()), "amk_swiglu_bf16_bwd")
+        return d_ab.view(ctx.shape)
+
+
+# Mixed precision: bf16-in / bf16-out element-wise kernels between the bf16 GEMMs (no separate cast passes);
+# AMK_MIXED_ELEMENTWISE=0 returns to the round-2 behaviour (inputs upcast, f32 kernels, outputs cast by autocast).
+MIXED_ELEMENTWISE = os.environ.get("AMK_MIXED_ELEMENTWISE", "1") == "1"
+
+
 def swiglu(ab):
     """silu(a) * b for ab = (..., 2H) = (a | b): one HBM pass forward, one backward."""
+    if MIXED_ELEMENTWISE and ab.dtype == torch.bfloat16 and ab.is_cuda and ab.shape[-1] % 8 == 0:
+        with torch.autocast("cuda", enabled=False):
+            return _SwiGLUBF16.apply(ab)
     return _f32_outside_autocast(_SwiGLU.apply, ab)
 
 
@@ -850,18 +882,84 @@ class _AddLayerNorm(torch.autograd.Function):
         return dh, dh, dw, db, None
 
 
-def layer_norm(x, weight, bias, eps=1e-5):
-    """LayerNorm over the last axis (one HBM pass forward, one backward incl. the gamma / beta partials)."""
-    if not _ln_supported(x.shape[-1]) or x.numel() == 0:
+class _AddLayerNormMixed(torch.autograd.Function):
+    """(x, res) -> (h, y) for the mixed-precision mode: x f32 or bf16 (a branch's output), res f32 (the residual stream)
+    or None; h = x + res in f32 (x itself without a residual), y = LN(h) in bf16 for the bf16 GEMMs that consume it.
+    Backward: dy bf16 or f32; the gradient of the residual stream stays f32, the branch gets it rounded to bf16."""
+
+    @staticmethod
+    def forward(ctx, x, res, weight, bias, eps):
+        _require_device(res, weight, bias)
+        D = x.shape[-1]
+        x2 = x.contiguous().view(-1, D)
+        M = x2.shape[0]
+        xb = x2.dtype == torch.bfloat16
+        if not xb and x2.dtype != torch.float32:
+            raise RuntimeError(f"mixed LayerNorm takes f32 or bf16 inputs, got {x2.dtype}")
+        r2 = res.contiguous().view(-1, D) if res is not None else None
+        need_h = r2 is not None or xb
+        h = torch.empty((M, D), device=x.device, dtype=torch.float32) if need_h else None
+        y = torch.empty((M, D), device=x.device, dtype=torch.bfloat16)
+        mean = torch.empty((M,), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        w, b = weight.contiguous(), bias.contiguous()
+        _lib.check(_lib.load().amk_add_layernorm_mixed_fwd(_ptr(x2), 1 if xb else 0, _ptr(r2), _ptr(w), _ptr(b), M, D, float(eps),
+                                                          _ptr(h), _ptr(y), _ptr(mean), _ptr(rstd), _stream()),
+                   "amk_add_layernorm_mixed_fwd")
+        hs = h if need_h else x2
+        ctx.save_for_backward(hs, w, mean, rstd)
+        ctx.cfg = (x.shape, xb, res is not None)
+        ctx.set_materialize_grads(False)
+        return hs.view(x.shape), y.view(x.shape)
+
+    @staticmethod
+    def backward(ctx, dh_in, dy):
+        h, w, mean, rstd = ctx.saved_tensors
+        shape, xb, has_res = ctx.cfg
+        M, D = h.shape
+        if dy is None:
+            if dh_in is None:
+                return None, None, None, None, None
+            dx = dh_in.to(torch.bfloat16) if xb else dh_in
+            return dx, (dh_in if has_res else None), None, None, None
+        dyb = dy.dtype == torch.bfloat16
+        dy2 = (dy if dyb else dy.float()).contiguous().view(M, D)
+        dh2 = dh_in.float().contiguous().view(M, D) if dh_in is not None else None
+        L = _lib.load()
+        dh = torch.empty((M, D), device=h.device, dtype=torch.float32)
+        dh16 = torch.empty((M, D), device=h.device, dtype=torch.bfloat16) if xb else None
+        part = torch.empty((L.amk_rowsum_num_partials(M), 2, D), device=h.device, dtype=torch.float32)
+        _lib.check(L.amk_add_layernorm_mixed_bwd(_ptr(dy2), 1 if dyb else 0, _ptr(h), _ptr(dh2), _ptr(w), _ptr(mean), _ptr(rstd),
+                                                 M, D, _ptr(dh), _ptr(dh16), _ptr(part), _stream()), "amk_add_layernorm_mixed_bwd")
+        dgb = part.sum(0)
+        dhv = dh.view(shape)
+        dx = dh16.view(shape) if xb else dhv
+        return dx, (dhv if has_res else None), dgb[0], dgb[1], None
+
+
+def _mixed_ln():
+    return (MIXED_ELEMENTWISE and torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)
+
+
+def layer_norm(x, weight, bias, eps=1e-5, branch=False):
+    """LayerNorm over the last axis (one HBM pass forward, one backward incl. the gamma / beta partials).
+    branch=True: the result only feeds Linear layers -- under bf16 autocast it is then produced in bf16 directly."""
+    if not _ln_supported(x.shape[-1]) or x.numel() == 0 or not x.is_cuda:
         return torch.nn.functional.layer_norm(x, (x.shape[-1],), weight, bias, eps)
+    if branch and _mixed_ln():
+        with torch.autocast("cuda", enabled=False):
+            return _AddLayerNormMixed.apply(x, None, weight, bias, eps)[1]
     return _LayerNorm.apply(x, weight, bias, eps)
 
 
-def add_layer_norm(x, res, weight, bias, eps=1e-5):
-    """h = x + res, y = LayerNorm(h): returns (h, y) from one kernel (amk_add_layernorm_fwd)."""
-    if not _ln_supported(x.shape[-1]) or x.numel() == 0:
+def add_layer_norm(x, res, weight, bias, eps=1e-5, branch=False):
+    """h = x + res, y = LayerNorm(h): returns (h, y) from one kernel (amk_add_layernorm_fwd).  branch: see layer_norm."""
+    if not _ln_supported(x.shape[-1]) or x.numel() == 0 or not x.is_cuda:
         h = x + res
         return h, torch.nn.functional.layer_norm(h, (h.shape[-1],), weight, bias, eps)
+    if branch and _mixed_ln():
+        with torch.autocast("cuda", enabled=False):
+            return _AddLayerNormMixed.apply(x, res.float(), weight, bias, eps)
     return _AddLayerNorm.apply(x, res, weight, bias, eps)
 
 

@@ -500,6 +500,24 @@ int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o
                       int64_t dk_sb, int64_t dk_st, int64_t dk_sh, int64_t dv_sb, int64_t dv_st, int64_t dv_sh,
                       float scale, void* stream);
 
+/* --------------------------------------------------------------------------
+ * Element-wise passes of the mixed-precision (bf16 autocast) mode: the ops of amk_swiglu_* / amk_add_layernorm_*
+ * (models/vitvqgan.py:20-61) reading and writing bf16 where the neighbouring GEMM is a bf16 GEMM, so that no separate
+ * cast pass runs (cfg/vitvqgan.yaml:73: nn.Linear in bf16, LayerNorm in f32).  Arithmetic in f32.
+ *   swiglu_bf16   : ab (M, 2H) bf16 -> out (M, H) bf16;  backward: ab, d_out bf16 -> d_ab (M, 2H) bf16
+ *   mixed LN fwd  : h = x (+ res): x f32 or bf16 (x_is_bf16), res f32 or NULL; h f32 (may be NULL without res and with
+ *                   f32 x), y = LN(h) * gamma + beta written as bf16, mean / rstd f32
+ *   mixed LN bwd  : dy bf16 or f32 (dy_is_bf16), h f32 -> dh f32 (+ dh_in), dh_bf16 = the same rounded to bf16 (or NULL);
+ *                   dgb_part as amk_add_layernorm_bwd
+ * -------------------------------------------------------------------------- */
+int amk_swiglu_bf16_fwd(const void* ab, int64_t M, int H, void* out, void* stream);
+int amk_swiglu_bf16_bwd(const void* ab, const void* d_out, int64_t M, int H, void* d_ab, void* stream);
+int amk_add_layernorm_mixed_fwd(const void* x, int x_is_bf16, const float* res, const float* gamma, const float* beta,
+                                int64_t M, int D, float eps, float* h, void* y_bf16, float* mean, float* rstd, void* stream);
+int amk_add_layernorm_mixed_bwd(const void* dy, int dy_is_bf16, const float* h, const float* dh_in, const float* gamma,
+                                const float* mean, const float* rstd, int64_t M, int D, float* dh, void* dh_bf16,
+                                float* dgb_part, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
