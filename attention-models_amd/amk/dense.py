@@ -170,3 +170,38 @@ def gemm_tn(y, x, *, y2=None, ln=None, want_bias=False):
     ws = torch.empty((nbytes // 4,), device=y.device, dtype=torch.float32) if nbytes else None
     _run(d, ws)
     return dw, dw2, db
+
+
+def _mat16(t, what):
+    if not t.is_cuda:
+        raise RuntimeError("amk ops run only on MI355X (HIP) tensors; got a CPU tensor. There is no CPU fallback.")
+    if t.dtype != torch.bfloat16 or t.dim() != 2:
+        raise RuntimeError(f"{what} must be a bf16 matrix, got {t.dtype} {tuple(t.shape)}")
+    if t.stride(1) != 1 or t.stride(0) % 8 or t.data_ptr() % 16:
+        t = t.contiguous()
+    return t
+
+
+def supported_bf16(N, K):
+    """Shapes amk_gemm_tn_bf16 takes: gradient rows and columns multiples of 8."""
+    return N > 0 and K > 0 and N % 8 == 0 and K % 8 == 0
+
+
+def gemm_tn_bf16(y, x, want_bias=False):
+    """(dW (N, K) f32, db (N,) f32 or None) = (y^T x, column sums of y) for bf16 y (M, N), x (M, K): the weight and bias
+    gradient of nn.Linear under autocast (csrc/gemm_bf16.hip)."""
+    y, x = _mat16(y, "y"), _mat16(x, "x")
+    M, N = y.shape
+    K = x.shape[1]
+    if x.shape[0] != M:
+        raise RuntimeError(f"gemm_tn_bf16: y has {M} rows, x {x.shape[0]}")
+    if not supported_bf16(N, K):
+        raise RuntimeError(f"gemm_tn_bf16: N and K must be multiples of 8, got {N}, {K}")
+    L = _lib.load()
+    dw = torch.empty(N, K, device=y.device, dtype=torch.float32)
+    db = torch.empty(N, device=y.device, dtype=torch.float32) if want_bias else None
+    nbytes = L.amk_gemm_tn_bf16_ws_bytes(M, N, K)
+    ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
+    rc = L.amk_gemm_tn_bf16(_p(y), y.stride(0), _p(x), x.stride(0), _p(dw), K, _p(db), M, N, K, _p(ws), nbytes, _stream())
+    _lib.check(rc, "amk_gemm_tn_bf16")
+    return dw, db

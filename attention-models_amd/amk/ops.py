@@ -1176,8 +1176,43 @@ class _SwiGLUFFN(torch.autograd.Function):
         return dx, dw12, db12, dw3, db3
 
 
+# AMK_MIXED_WGRAD=0: nn.Linear under bf16 autocast entirely by the library and autograd (the round-2 behaviour).
+MIXED_WGRAD = os.environ.get("AMK_MIXED_WGRAD", "1") == "1"
+
+
+class _LinearMixed(torch.autograd.Function):
+    """nn.Linear under bf16 autocast: forward and input gradient by the library's bf16 GEMMs as autocast runs them,
+    weight and bias gradient by amk_gemm_tn_bf16 -- one pass over dY and X, f32 results (csrc/gemm_bf16.hip; the library
+    runs these products at 50-180 TFLOP/s, rounds dW to bf16 and leaves db to a separate reduction)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x16, w16 = x.to(torch.bfloat16), weight.to(torch.bfloat16)
+        ctx.save_for_backward(x16, w16)
+        ctx.has_bias, ctx.x_dtype = bias is not None, x.dtype
+        return torch.nn.functional.linear(x16, w16, None if bias is None else bias.to(torch.bfloat16))
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import dense
+
+        x16, w16 = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dx = dy2.mm(w16).view(x16.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        dw, db = dense.gemm_tn_bf16(dy2, x16.reshape(-1, x16.shape[-1]), want_bias=ctx.has_bias)
+        return dx, dw, db
+
+
+def _mixed_linear_ok(x, weight):
+    return (MIXED_WGRAD and x.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16 and torch.is_grad_enabled()
+            and weight.requires_grad and weight.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16)
+            and weight.shape[0] % 8 == 0 and weight.shape[1] % 8 == 0 and x.numel() > 0)
+
+
 def linear(x, weight, bias=None):
-    if torch.is_autocast_enabled():  # mixed precision: the library GEMM in the autocast dtype, bias gradient by autograd
+    if torch.is_autocast_enabled():  # mixed precision: the library GEMMs in the autocast dtype, own weight gradient
+        if _mixed_linear_ok(x, weight):
+            return _LinearMixed.apply(x, weight, bias)
         return torch.nn.functional.linear(x, weight, bias)
     if GEMM_MODE == "bf16x6" and _x6_ok(x, weight):
         return _LinearX6.apply(x, weight, bias)

@@ -1,0 +1,279 @@
+// Weight (and bias) gradient of nn.Linear in the mixed-precision mode: dW[n, k] = sum_m dY[m, n] X[m, k] with dY
+// (M, N) and X (M, K) in bf16 as the autocast GEMMs leave them, dW and db in f32 as the parameters' gradients are
+// kept (reference: the backward of nn.Linear in models/softmax_attention.py:30-42,80 and models/vitvqgan.py:20-34
+// under cfg/vitvqgan.yaml:73).  The vendor library runs these products -- tiny outputs, a contraction over all
+// B*T rows -- at 70-300 TFLOP/s (90-150 us each at batch 32) and the bias gradients as separate reductions; they are
+// HBM-bound: every byte of dY and X has to be read once and that is all.
+//   tile 128 (n) x 128 (k), four waves as 2 x 2 of 64 x 64, v_mfma_f32_32x32x16_bf16; the M rows in chunks so that
+//   tiles x chunks fills the chip four workgroups deep; partial tiles (f32) through a workspace, summed in chunk order
+//   (bitwise reproducible); both operands are staged AS STORED -- [32 rows][128 columns] bf16, row stride 320 B -- and
+//   both MFMA operands (whose contraction index is the row) come from ds_read_b64_tr_b16, 4 rows x 64 B per
+//   half-wave on 64 distinct banks; db = column sums of the staged dY pieces (first k tile only).
+#include "amk_common.h"
+#include <stdlib.h>
+
+namespace amk_gemm16 {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int STR = 160;     // bf16 per LDS row: 128 + 32 (80 dwords = 16 mod 64: conflict-free transposing reads)
+constexpr unsigned COL_PAST = 0x40000000u;
+
+struct Params {
+  const __bf16 *y, *x;
+  float *c, *dbias, *ws, *dbias_ws;
+  int64_t M, ldy, ldx, ldc;
+  int N, K, ntk, total, nchunk, steps_per_chunk;
+};
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+__device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
+  const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  return __builtin_bit_cast(bf16x4, v);
+}
+// 32x32x16 operand whose contraction index is the ROW of the LDS tile, natural order: lane (col = c0 + (l & 31), half)
+// gets rows r0 + 8 half + (0..7)
+__device__ __forceinline__ bf16x8 tr_frag(const __bf16* img, int r0, int c0, int lane) {
+  const int hf = lane >> 5, grp = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
+  const __bf16* a = img + (r0 + 8 * hf + q) * STR + c0 + 16 * grp + 4 * pp;
+  const bf16x4 lo = tr_read(a), hi = tr_read(a + 4 * STR);
+  bf16x8 r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { r[i] = lo[i]; r[4 + i] = hi[i]; }
+  return r;
+}
+
+// BKM: rows of the contraction per step
+template <int BKM>
+__global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Params p) {
+  constexpr int OPER = BKM * STR, NP = BKM / 16;   // elements of one operand tile; 16-byte pieces per thread and operand
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 2 * OPER];   // 2 stages x {Y tile, X tile}
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int u = xcd_remap(blockIdx.x, p.total);
+  // unit order (n tile, chunk, k tile): the k tiles that read the same dY panel are neighbours (one XCD, one L2)
+  const int tk = u % p.ntk, rest = u / p.ntk;
+  const int tn = rest / p.nchunk, chunk = rest - tn * p.nchunk;
+  const int n0 = tn * 128, k0 = tk * 128;
+  const int64_t mbeg = (int64_t)chunk * p.steps_per_chunk * BKM;
+  int64_t mend = mbeg + (int64_t)p.steps_per_chunk * BKM;
+  if (mend > p.M) mend = p.M;
+  const int mrows = (int)(mend - mbeg);
+  const int nk = (mrows + BKM - 1) / BKM;
+
+  // staging: a 32 x 128 tile = 512 pieces of 16 B: thread -> column group cg (8 columns), rows sr and sr + 16
+  const int cg = tid & 15, sr = tid >> 4;
+  const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + mbeg * p.ldy), 0, (int)(((int64_t)(mrows - 1) * p.ldy + p.N) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + mbeg * p.ldx), 0, (int)(((int64_t)(mrows - 1) * p.ldx + p.K) * 2), 0x00020000);
+  const bool yok = n0 + 8 * cg < p.N, xok = k0 + 8 * cg < p.K;   // (N and K multiples of 8: a piece is in or out)
+  unsigned yoff[NP], xoff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    yoff[i] = yok ? (unsigned)(((int64_t)(sr + 16 * i) * p.ldy + n0 + 8 * cg) * 2) : COL_PAST;
+    xoff[i] = xok ? (unsigned)(((int64_t)(sr + 16 * i) * p.ldx + k0 + 8 * cg) * 2) : COL_PAST;
+  }
+  const unsigned ystep = (unsigned)(BKM * p.ldy * 2), xstep = (unsigned)(BKM * p.ldx * 2);
+  struct Stg { float4 y[NP], x[NP]; };
+  auto gload = [&](Stg& g, int t) {
+    const int tt = t < nk ? t : nk - 1;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      g.y[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, (int)(yoff[i] + (unsigned)tt * ystep), 0, 0));
+      g.x[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(xoff[i] + (unsigned)tt * xstep), 0, 0));
+    }
+  };
+  const bool do_bias = p.dbias != nullptr && tk == 0;
+  float bsum[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
+  auto lstore = [&](__bf16* stage, const Stg& g, bool count) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      *reinterpret_cast<float4*>(&stage[(sr + 16 * i) * STR + 8 * cg]) = g.y[i];
+      *reinterpret_cast<float4*>(&stage[OPER + (sr + 16 * i) * STR + 8 * cg]) = g.x[i];
+      if (do_bias && count) {
+        const bf16x8 v = __builtin_bit_cast(bf16x8, g.y[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bsum[j] += (float)v[j];
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  // two tiles in flight in registers (sets ga, gb) beside the one being staged: a step is a few hundred cycles, HBM
+  // latency several thousand
+  Stg ga, gb;
+  gload(ga, 0);
+  gload(gb, 1);
+  lstore(smem, ga, true);
+  gload(ga, 2);
+  __syncthreads();
+  auto step = [&](int t, Stg& g) {
+    const __bf16* cur = smem + (t & 1) * 2 * OPER;
+    __bf16* nxt = smem + ((t + 1) & 1) * 2 * OPER;
+    lstore(nxt, g, t + 1 < nk);   // tile t+1 (loaded two steps ago) -> the other stage; then fetch tile t+3
+    gload(g, t + 3);
+#pragma unroll
+    for (int s = 0; s < BKM / 16; ++s) {
+      const bf16x8 a0 = tr_frag(cur, 16 * s, 64 * wn, lane), a1 = tr_frag(cur, 16 * s, 64 * wn + 32, lane);
+      const bf16x8 b0 = tr_frag(cur + OPER, 16 * s, 64 * wk, lane), b1 = tr_frag(cur + OPER, 16 * s, 64 * wk + 32, lane);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    step(t, gb);
+    if (t + 1 < nk) step(t + 1, ga);
+  }
+  // ---- the partial tile: rows n0 + 64 wn + 32 i + (r & 3) + 8 (r >> 2) + 4 hf, column k0 + 64 wk + 32 j + ln
+  float* Cb = p.nchunk > 1 ? p.ws + (int64_t)chunk * p.N * p.K : p.c;
+  const int64_t ldc = p.nchunk > 1 ? p.K : p.ldc;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int kc = k0 + 64 * wk + 32 * j + ln;
+      if (kc < p.K) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + 64 * wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf;
+          if (n < p.N) Cb[(int64_t)n * ldc + kc] = acc[i][j][r];
+        }
+      }
+    }
+  }
+  if (do_bias) {   // fold the 16 row groups (sr) of each column group
+    float* red = reinterpret_cast<float*>(smem);   // (the loop ended with a barrier)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[sr * 128 + 8 * cg + j] = bsum[j];
+    __syncthreads();
+    if (tid < 128) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += red[r * 128 + tid];
+      const int n = n0 + tid;
+      if (n < p.N) (p.nchunk > 1 ? p.dbias_ws + (int64_t)chunk * p.N : p.dbias)[n] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tn_bf16_reduce_kernel(Params p) {
+  const int64_t total4 = (int64_t)p.N * p.K / 4, slab = (int64_t)p.N * p.K;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < total4) {
+    const float* src = p.ws + 4 * i;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    int c = 0;
+    for (; c + 8 <= p.nchunk; c += 8) {
+      float4 v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(src + (c + j) * slab);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s.x += v[j].x; s.y += v[j].y; s.z += v[j].z; s.w += v[j].w; }
+    }
+    for (; c < p.nchunk; ++c) {
+      const float4 v = *reinterpret_cast<const float4*>(src + c * slab);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const int64_t e = 4 * i, row = e / p.K;
+    *reinterpret_cast<float4*>(p.c + row * p.ldc + (e - row * p.K)) = s;
+  }
+  if (p.dbias && i < p.N) {   // thread n also folds the bias partials of column n (the launch has at least N threads)
+    float s = 0.f;
+    for (int c = 0; c < p.nchunk; ++c) s += p.dbias_ws[(int64_t)c * p.N + i];
+    p.dbias[i] = s;
+  }
+}
+
+}  // namespace amk_gemm16
+
+using namespace amk_gemm16;
+
+static int step_rows() {
+  static int bkm = 0;
+  if (bkm == 0) {
+    const char* e = getenv("AMK_TN16_BKM");
+    bkm = e && atoi(e) == 32 ? 32 : 64;
+  }
+  return bkm;
+}
+
+static int chunks_for(int64_t M, int N, int K, int* spc) {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  }
+  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
+  const int BKM = step_rows();
+  const int64_t steps = (M + BKM - 1) / BKM;
+  static int wgs = 0;
+  if (wgs == 0) {
+    const char* e = getenv("AMK_TN16_WGS");
+    wgs = e && atoi(e) > 0 ? atoi(e) : 2;   // workgroups per CU the grid aims at (more: more partial tiles to write and re-read)
+  }
+  int64_t chunks = ((int64_t)wgs * cus) / tiles;
+  if (chunks < 1) chunks = 1;
+  if (chunks > steps / 8) chunks = steps / 8 > 0 ? steps / 8 : 1;
+  int64_t s = (steps + chunks - 1) / chunks;
+  chunks = (steps + s - 1) / s;
+  *spc = (int)s;
+  return (int)chunks;
+}
+
+extern "C" int64_t amk_gemm_tn_bf16_ws_bytes(int64_t M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return 0;
+  int spc;
+  const int chunks = chunks_for(M, N, K, &spc);
+  return chunks > 1 ? ((int64_t)chunks * N * K + (int64_t)chunks * N) * 4 : 0;
+}
+
+extern "C" int amk_gemm_tn_bf16(const void* y, int64_t ldy, const void* x, int64_t ldx, float* c, int64_t ldc, float* dbias,
+                                int64_t M, int N, int K, void* workspace, int64_t ws_bytes, void* stream) {
+  AMK_CHECK_ARG(y && x && c, "amk_gemm_tn_bf16: null operand");
+  AMK_CHECK_ARG(M > 0 && N > 0 && K > 0, "amk_gemm_tn_bf16: non-positive size");
+  AMK_CHECK_SUPPORTED(N % 8 == 0 && K % 8 == 0 && ldy % 8 == 0 && ldx % 8 == 0 && ldc % 4 == 0,
+                      "amk_gemm_tn_bf16: N, K and the bf16 leading dimensions must be multiples of 8, ldc of 4");
+  AMK_CHECK_ARG(((uintptr_t)y & 15) == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)c & 15) == 0, "amk_gemm_tn_bf16: pointers must be 16-byte aligned");
+  Params p = {};
+  p.y = static_cast<const __bf16*>(y); p.x = static_cast<const __bf16*>(x); p.c = c; p.dbias = dbias;
+  p.M = M; p.N = N; p.K = K; p.ldy = ldy; p.ldx = ldx; p.ldc = ldc;
+  int spc;
+  p.nchunk = chunks_for(M, N, K, &spc);
+  p.steps_per_chunk = spc;
+  const int BKM = step_rows();
+  AMK_CHECK_SUPPORTED((int64_t)spc * BKM * ldy * 2 < (1ll << 30) && (int64_t)spc * BKM * ldx * 2 < (1ll << 30), "amk_gemm_tn_bf16: chunk panel beyond 1 GiB");
+  if (p.nchunk > 1) {
+    AMK_CHECK_ARG(workspace && ws_bytes >= amk_gemm_tn_bf16_ws_bytes(M, N, K) && ((uintptr_t)workspace & 15) == 0,
+                  "amk_gemm_tn_bf16: workspace of amk_gemm_tn_bf16_ws_bytes() bytes (16-byte aligned) required");
+    p.ws = static_cast<float*>(workspace);
+    p.dbias_ws = p.ws + (int64_t)p.nchunk * N * K;
+  }
+  p.ntk = (K + 127) / 128;
+  const int64_t total = (int64_t)((N + 127) / 128) * p.ntk * p.nchunk;
+  AMK_CHECK_SUPPORTED(total < (1ll << 31), "amk_gemm_tn_bf16: grid too large");
+  p.total = (int)total;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (BKM == 32) hipLaunchKernelGGL(gemm_tn_bf16_kernel<32>, dim3((unsigned)total), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(gemm_tn_bf16_kernel<64>, dim3((unsigned)total), dim3(256), 0, st, p);
+  if (p.nchunk > 1) {
+    int64_t blocks = ((int64_t)N * K / 4 + 255) / 256;
+    if (blocks < (N + 255) / 256) blocks = (N + 255) / 256;   // (thread n also folds the bias partials of column n)
+    hipLaunchKernelGGL(tn_bf16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+  }
+  AMK_CHECK_LAUNCH("amk_gemm_tn_bf16");
+  return AMK_OK;
+}

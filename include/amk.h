@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 130 /* 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
+#define AMK_VERSION 131 /* 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
 
 enum {
   AMK_OK = 0,
@@ -517,6 +517,15 @@ int amk_add_layernorm_mixed_fwd(const void* x, int x_is_bf16, const float* res, 
 int amk_add_layernorm_mixed_bwd(const void* dy, int dy_is_bf16, const float* h, const float* dh_in, const float* gamma,
                                 const float* mean, const float* rstd, int64_t M, int D, float* dh, void* dh_bf16,
                                 float* dgb_part, void* stream);
+
+/* Weight and bias gradient of nn.Linear in the mixed-precision mode (csrc/gemm_bf16.hip): c[n, k] = sum_m y[m, n] x[m, k]
+ * with y (M, N) and x (M, K) in bf16 as the autocast GEMMs leave them, c (N, K) and dbias (N, optional: column sums of y)
+ * in f32 as the parameters' gradients are kept.  Replaces the autograd backward of nn.Linear under torch.autocast
+ * (reference: models/softmax_attention.py:30-42,80, models/vitvqgan.py:20-34 under cfg/vitvqgan.yaml:73).  N, K, ldy, ldx
+ * multiples of 8, ldc of 4; sums in a fixed order (bitwise reproducible).  workspace: amk_gemm_tn_bf16_ws_bytes(). */
+int64_t amk_gemm_tn_bf16_ws_bytes(int64_t M, int N, int K);
+int amk_gemm_tn_bf16(const void* y, int64_t ldy, const void* x, int64_t ldx, float* c, int64_t ldc, float* dbias,
+                     int64_t M, int N, int K, void* workspace, int64_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }
