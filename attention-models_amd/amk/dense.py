@@ -205,3 +205,57 @@ def gemm_tn_bf16(y, x, want_bias=False):
     rc = L.amk_gemm_tn_bf16(_p(y), y.stride(0), _p(x), x.stride(0), _p(dw), K, _p(db), M, N, K, _p(ws), nbytes, _stream())
     _lib.check(rc, "amk_gemm_tn_bf16")
     return dw, db
+
+
+def _bias32(bias, n):
+    if bias is None:
+        return None
+    if bias.dtype != torch.float32 or not bias.is_cuda:
+        raise RuntimeError("gemm bf16: the bias stays in fp32 (it is added to the fp32 accumulators)")
+    bias = bias.contiguous()
+    if bias.numel() != n or bias.data_ptr() % 16:
+        raise RuntimeError(f"gemm bf16: bias of {bias.numel()} elements (16-byte aligned) expected {n}")
+    return bias
+
+
+def gemm_nt_bf16(a, w, bias=None):
+    """a (M, K) w (N, K)^T + bias -> (M, N), bf16 in and out, fp32 accumulation and bias (csrc/gemm_bf16.hip)."""
+    a, w = _mat16(a, "a"), _mat16(w, "w")
+    (M, K), N = a.shape, w.shape[0]
+    if w.shape[1] != K or not supported_bf16(N, K):
+        raise RuntimeError(f"gemm_nt_bf16: a {tuple(a.shape)} x w {tuple(w.shape)}^T (multiples of 8 required)")
+    bias = _bias32(bias, N)
+    c = torch.empty(M, N, device=a.device, dtype=torch.bfloat16)
+    if M:
+        rc = _lib.load().amk_gemm_bf16(0, 0, _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(c), N, _p(None), 0, M, N, K, _stream())
+        _lib.check(rc, "amk_gemm_bf16")
+    return c
+
+
+def gemm_nn_bf16(a, w):
+    """a (M, K) w (K, N) -> (M, N): the input gradient dY W with W as nn.Linear stores it."""
+    a, w = _mat16(a, "a"), _mat16(w, "w")
+    (M, K), N = a.shape, w.shape[1]
+    if w.shape[0] != K or not supported_bf16(N, K):
+        raise RuntimeError(f"gemm_nn_bf16: a {tuple(a.shape)} x w {tuple(w.shape)} (multiples of 8 required)")
+    c = torch.empty(M, N, device=a.device, dtype=torch.bfloat16)
+    if M:
+        rc = _lib.load().amk_gemm_bf16(1, 0, _p(a), a.stride(0), _p(w), w.stride(0), _p(None), _p(c), N, _p(None), 0, M, N, K, _stream())
+        _lib.check(rc, "amk_gemm_bf16")
+    return c
+
+
+def gemm_nt_swiglu_bf16(a, w12, b12=None, keep_ab=True):
+    """(g, ab): ab = a w12^T + b12 (M, 2 H), g = silu(ab[:, :H]) * ab[:, H:] (M, H) from one launch; ab is None with
+    keep_ab=False."""
+    a, w12 = _mat16(a, "a"), _mat16(w12, "w12")
+    (M, K), N = a.shape, w12.shape[0]
+    if w12.shape[1] != K or N % 16 or K % 8:
+        raise RuntimeError(f"gemm_nt_swiglu_bf16: a {tuple(a.shape)} x w12 {tuple(w12.shape)}^T (2 H a multiple of 16, K of 8)")
+    b12 = _bias32(b12, N)
+    g = torch.empty(M, N // 2, device=a.device, dtype=torch.bfloat16)
+    ab = torch.empty(M, N, device=a.device, dtype=torch.bfloat16) if keep_ab else None
+    if M:
+        rc = _lib.load().amk_gemm_bf16(0, 1, _p(a), a.stride(0), _p(w12), w12.stride(0), _p(b12), _p(ab), N, _p(g), N // 2, M, N, K, _stream())
+        _lib.check(rc, "amk_gemm_bf16")
+    return g, ab

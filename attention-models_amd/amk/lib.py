@@ -83,6 +83,7 @@ SIGNATURES = {
     "amk_swiglu_bf16_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
     "amk_add_layernorm_mixed_fwd": (_I, [_P, _I, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
     "amk_add_layernorm_mixed_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
+    "amk_gemm_bf16": (_I, [_I, _I, _P, _L, _P, _L, _P, _P, _L, _P, _L, _L, _I, _I, _P]),
     "amk_gemm_tn_bf16_ws_bytes": (_L, [_L, _I, _I]),
     "amk_gemm_tn_bf16": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _P]),
     "amk_sample_step": (_I, [_P, _P, _F, _P, _c.c_uint64, _c.c_uint64, _F, _L, _I, _I, _P, _F, _P, _P, _P]),

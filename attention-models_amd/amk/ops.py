@@ -1230,8 +1230,46 @@ def linear2(x, wa, wb):
     return linear(x, wa), linear(x, wb)
 
 
+class _SwiGLUFFNMixed(torch.autograd.Function):
+    """The SwiGLU FFN under bf16 autocast (models/vitvqgan.py:20-34 under cfg/vitvqgan.yaml:73): w12 with the gate in its
+    epilogue (amk_gemm_bf16, epi 1: (a | b) and silu(a) b from one launch), the gate's input gradient dY W3 by
+    amk_gemm_bf16 (op 1), both weight / bias gradients by amk_gemm_tn_bf16; w3's forward and w12's input gradient stay
+    on the library, which is faster on those two shapes (tools/kbench_tn_bf16.py)."""
+
+    @staticmethod
+    def forward(ctx, x, w12, b12, w3, b3):
+        from . import dense
+
+        x16 = x.to(torch.bfloat16).reshape(-1, x.shape[-1])
+        w12h, w3h = w12.to(torch.bfloat16), w3.to(torch.bfloat16)
+        g, ab = dense.gemm_nt_swiglu_bf16(x16, w12h, b12)
+        y = torch.nn.functional.linear(g, w3h, None if b3 is None else b3.to(torch.bfloat16))
+        ctx.save_for_backward(x16, ab, g, w12h, w3h)
+        ctx.x_shape, ctx.x_dtype, ctx.bias = x.shape, x.dtype, (b12 is not None, b3 is not None)
+        return y.view(*x.shape[:-1], w3.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import dense
+
+        x16, ab, g, w12h, w3h = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1])
+        dw3, db3 = dense.gemm_tn_bf16(dy2, g, want_bias=ctx.bias[1])
+        dg = dense.gemm_nn_bf16(dy2, w3h)
+        dab = torch.empty_like(ab)
+        M, H2 = ab.shape
+        _lib.check(_lib.load().amk_swiglu_bf16_bwd(_ptr(ab), _ptr(dg), M, H2 // 2, _ptr(dab), _stream()), "amk_swiglu_bf16_bwd")
+        dw12, db12 = dense.gemm_tn_bf16(dab, x16, want_bias=ctx.bias[0])
+        dx = dab.mm(w12h).view(ctx.x_shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
+        return dx, dw12, db12, dw3, db3
+
+
 def swiglu_ffn(x, w12, b12, w3, b3):
     """w3(silu(a) * b), (a | b) = w12(x): fused (see _SwiGLUFFN) when the shapes allow, else the separate launches."""
+    if (torch.is_autocast_enabled() and _mixed_linear_ok(x, w12) and _mixed_linear_ok(x, w3) and w3.requires_grad
+            and w12.shape[0] % 16 == 0 and w12.shape[0] >= 1024):
+        with torch.autocast("cuda", enabled=False):
+            return _SwiGLUFFNMixed.apply(x, w12, b12, w3, b3)
     if GEMM_MODE != "bf16x6" and _dense_ok(x, w12) and w3.shape[1] % 4 == 0 and w3.shape[0] % 4 == 0 and w3.is_contiguous():
         return _SwiGLUFFN.apply(x, w12, b12, w3, b3)
     ab = linear(x, w12, b12)

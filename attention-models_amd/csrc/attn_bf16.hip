@@ -37,7 +37,7 @@ struct Params {
   const __bf16 *q, *k, *v, *o, *d_o;
   __bf16 *out, *dq, *dk, *dv;
   float* stats;        // (B, H, I, 2): row max in the log2 domain, row sum
-  float* delta;        // (B, H, I): rowsum(dO * O)
+  float* delta;        // (B, H, I) x 2: the backward row constants {-(m + log2 l) / c2, -rowsum(dO * O)}
   float* dq_part;      // (nkblk, B, I, H, 64) f32
   int B, H, I, J;
   Strides qs, ks, vs, os, dos, dqs, dks, dvs;
@@ -235,9 +235,18 @@ __global__ __launch_bounds__(256) void attn_bf16_delta_kernel(Params p) {
   for (int e = 0; e < 4; ++e) s += (float)a[e] * (float)c[e];
 #pragma unroll
   for (int o = 8; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (part == 0) p.delta[row] = s;
+  if (part == 0) {
+    // the row constants as the backward's MFMA chains start from them: S' = q.k - (m + log2 l) / c2 (so that
+    // P = exp2(c2 S') comes out normalised) and dP' = dO.v - delta
+    const float m = p.stats[2 * row], l = p.stats[2 * row + 1];
+    const float c2 = p.scale * AMK_LOG2E;
+    reinterpret_cast<float2*>(p.delta)[row] = make_float2(-(m + __builtin_log2f(l)) / c2, -s);
+  }
 }
 
+#ifndef A16_ABLATE
+#define A16_ABLATE 0   // timing experiments only (tools/ablate_attn_bf16.sh): bits switch parts of the backward off
+#endif
 constexpr int BW = 8;            // waves per backward workgroup
 constexpr int BKEYS = 32 * BW;   // keys per workgroup
 constexpr int DSTR = 48;         // bf16 per row of the dS^T image [key][32 queries]
@@ -258,7 +267,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   __bf16* dSs = Kt + BKEYS * TSTR;                                  // 2 x [256 keys][DSTR]
   __bf16* tiles = dSs + 2 * BKEYS * DSTR;                           // 2 stages x {Qrow, Qtr, dOrow, dOtr}
   constexpr int STG = 2 * (32 * KSTR + 32 * TSTR);
-  float* stat = reinterpret_cast<float*>(tiles + 2 * STG);          // 2 stages x {m, 1/l, delta} x 32
+  float* stat = reinterpret_cast<float*>(tiles + 2 * STG);          // 2 stages x {-(m + log2 l) / c2, -delta} x 32
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -298,61 +307,69 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   const int64_t tst = isq ? p.qs.st : p.dos.st;
   const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tbase, 0, (int)(((int64_t)(p.I - 1) * tst + 64) * 2), 0x00020000);
   const int toff = (int)(((int64_t)prow * tst + pch) * 2), tstep = (int)(32 * tst * 2);
-  const float* stp = p.stats + ((int64_t)bh * p.I) * 2;
-  const float* dlp = p.delta + (int64_t)bh * p.I;
-  float4 piece;
-  float st_m = 0.f, st_li = 0.f, st_d = 0.f;
+  const float2* rcp = reinterpret_cast<const float2*>(p.delta) + (int64_t)bh * p.I;
+  float4 piece[2];                        // two tiles in flight (a tile is ~1 us of work, a load up to 2 us away)
+  float2 st_rc[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
   const int ntile = (p.I + 31) / 32;
-  auto prefetch = [&](int t) {
-    piece = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(t_rsrc, toff + t * tstep, 0, 0));
+  auto prefetch = [&](int t, int slot) {
+    piece[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(t_rsrc, toff + t * tstep, 0, 0));
     if (tid < 32) {
       const int i = t * 32 + tid;
-      st_m = 0.f; st_li = 0.f; st_d = 0.f;
-      if (i < p.I) { st_m = stp[2 * i]; st_li = 1.f / stp[2 * i + 1]; st_d = dlp[i]; }
+      st_rc[slot] = i < p.I ? rcp[i] : make_float2(-1e30f, 0.f);   // (rows past the sequence: P = 0)
     }
   };
-  auto commit = [&](int stage) {
+  auto commit = [&](int stage, int slot) {
     __bf16* base = tiles + stage * STG + (isq ? 0 : 32 * KSTR + 32 * TSTR);
-    *reinterpret_cast<float4*>(&base[prow * KSTR + pch]) = piece;                  // row-read image
-    *reinterpret_cast<float4*>(&base[32 * KSTR + prow * TSTR + pch]) = piece;      // transposed-read image
+    *reinterpret_cast<float4*>(&base[prow * KSTR + pch]) = piece[slot];                  // row-read image
+    *reinterpret_cast<float4*>(&base[32 * KSTR + prow * TSTR + pch]) = piece[slot];      // transposed-read image
     if (tid < 32) {
-      float* sb = stat + stage * 96;
-      sb[tid] = st_m; sb[32 + tid] = st_li; sb[64 + tid] = st_d;
+      float* sb = stat + stage * 64;
+      sb[tid] = st_rc[slot].x; sb[32 + tid] = st_rc[slot].y;
     }
   };
   const float c2 = p.scale * AMK_LOG2E;
   f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
   const bool tail_keys = key0 + BKEYS > p.J;   // some of the workgroup's keys are past the sequence
-  prefetch(0);
-  commit(0);
-  if (ntile > 1) prefetch(1);
+  prefetch(0, 0);
+  commit(0, 0);
+  prefetch(1, 1);   // (tiles past the end: the descriptor returns zeros and nothing is committed)
+  prefetch(2, 0);
   __syncthreads();
   float* dqp = p.dq_part + (((int64_t)kb * p.B + b) * p.I * p.H + h) * 64;   // [kb][b][i][h][d]
+  // dQ: wave w owns the 16 x 16 block (queries 16 (w & 1), dims 16 (w >> 1)) of every tile, so its K operands -- the
+  // same for every tile -- stay in registers
+  const int qblk = wave & 1, dblk = wave >> 1;
+  bf16x8 kq[BKEYS / 32];
+#pragma unroll
+  for (int ks = 0; ks < BKEYS / 32; ++ks) kq[ks] = tr_frag16(Kt, TSTR, 32 * ks, 16 * dblk, lane);
   auto dq_tile = [&](int tt) {
     const __bf16* img = dSs + (tt & 1) * BKEYS * DSTR;
-    const int qblk = wave & 1, dblk = wave >> 1;
+    // the dQ^T block (dims x queries), so that a lane ends with four consecutive dims of ONE query: a 16-byte store
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < BKEYS / 32; ++ks) {
-      const bf16x8 a = tr_frag16(img, DSTR, 32 * ks, 16 * qblk, lane);
-      const bf16x8 bb = tr_frag16(Kt, TSTR, 32 * ks, 16 * dblk, lane);
-      acc = mfma16(a, bb, acc);
-    }
-    const int i0 = tt * 32 + 16 * qblk + 4 * (lane >> 4);
-    float* o = dqp + (int64_t)i0 * p.H * 64 + 16 * dblk + (lane & 15);
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (i0 + r < p.I) o[(int64_t)r * p.H * 64] = acc[r];
+    for (int ks = 0; ks < BKEYS / 32; ++ks) acc = mfma16(kq[ks], tr_frag16(img, DSTR, 32 * ks, 16 * qblk, lane), acc);
+    const int i = tt * 32 + 16 * qblk + (lane & 15);
+    if ((A16_ABLATE & 1) ? acc[0] == 12345.f : i < p.I)
+      *reinterpret_cast<float4*>(dqp + (int64_t)i * p.H * 64 + 16 * dblk + 4 * (lane >> 4)) =
+          make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
   };
-  for (int t = 0; t < ntile; ++t) {
+  auto tile_step = [&](int t, int slot) {   // slot: where tile t + 1 waits in registers
     const int sg = t & 1;
     const __bf16* Qrow = tiles + sg * STG;
     const __bf16* Qtr = Qrow + 32 * KSTR;
     const __bf16* dOrow = Qtr + 32 * TSTR;
     const __bf16* dOtr = dOrow + 32 * KSTR;
-    const float* sb = stat + sg * 96;
-    // ---- S = Q K^T, dP = dO V^T: rows = queries, columns = keys (this lane's key)
-    f32x16 s = zero16(), dp = zero16();
+    const float* sb = stat + sg * 64;
+    // ---- S' = Q K^T - lse / c2, dP' = dO V^T - delta: rows = queries (registers r <-> rows 8 g + 4 half + e of the
+    //      tile), columns = keys (this lane's key); the row constants are the chains' initial accumulators
+    f32x16 s, dp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 a4 = *reinterpret_cast<const float4*>(&sb[8 * g + 4 * hf]);
+      const float4 d4 = *reinterpret_cast<const float4*>(&sb[32 + 8 * g + 4 * hf]);
+      s[4 * g] = a4.x; s[4 * g + 1] = a4.y; s[4 * g + 2] = a4.z; s[4 * g + 3] = a4.w;
+      dp[4 * g] = d4.x; dp[4 * g + 1] = d4.y; dp[4 * g + 2] = d4.z; dp[4 * g + 3] = d4.w;
+    }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
       const bf16x8 qa = *reinterpret_cast<const bf16x8*>(&Qrow[ln * KSTR + 16 * c + 8 * hf]);
@@ -360,23 +377,16 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
       s = mfmab(qa, kf[c], s);
       dp = mfmab(da, vf[c], dp);
     }
-    // ---- P and dS (registers r <-> query rows 8 g + 4 half + e of the tile)
+    // ---- dQ of the previous tile (32 queries x 64 dims) = dS (32 x 256 keys) K (256 x 64): issued here, behind the
+    //      S / dP chains in the matrix pipe, so that it runs under the exp work below
+    if (t > 0 && !(A16_ABLATE & 2)) dq_tile(t - 1);
+    // ---- P = exp2(c2 S'), dS / scale = P dP' (the scale goes onto dK and dQ where they are stored)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 m4 = *reinterpret_cast<const float4*>(&sb[8 * g + 4 * hf]);
-      const float4 l4 = *reinterpret_cast<const float4*>(&sb[32 + 8 * g + 4 * hf]);
-      const float4 d4 = *reinterpret_cast<const float4*>(&sb[64 + 8 * g + 4 * hf]);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int r = 4 * g + e;
-        const float mm = e == 0 ? m4.x : (e == 1 ? m4.y : (e == 2 ? m4.z : m4.w));
-        const float li = e == 0 ? l4.x : (e == 1 ? l4.y : (e == 2 ? l4.z : l4.w));
-        const float dl = e == 0 ? d4.x : (e == 1 ? d4.y : (e == 2 ? d4.z : d4.w));
-        float pr = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], c2, -mm)) * li;
-        if (tail_keys) pr = kvalid ? pr : 0.f;
-        s[r] = pr;
-        dp[r] = pr * (dp[r] - dl) * p.scale;
-      }
+    for (int r = 0; r < 16; ++r) {
+      float pr = (A16_ABLATE & 8) ? s[r] : __builtin_amdgcn_exp2f(s[r] * c2);
+      if (tail_keys) pr = kvalid ? pr : 0.f;
+      s[r] = pr;
+      dp[r] *= pr;
     }
     // ---- dS^T image for dQ: this lane's key row, its 16 queries as four 8-byte pieces (image t & 1: the dQ product
     //      of tile t runs in the NEXT iteration, beside that tile's S / dP work, so one barrier per tile is enough)
@@ -390,21 +400,22 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
         *reinterpret_cast<bf16x4*>(row + 8 * g) = w;
       }
     }
-    // ---- dQ of the previous tile (32 queries x 64 dims) = dS (32 x 256 keys) K (256 x 64): wave w owns the
-    //      16 x 16 block (w & 1, w >> 1)
-    if (t > 0) dq_tile(t - 1);
     // ---- dV^T += dO^T P, dK^T += Q^T dS (sums over the tile's 32 queries: two 16-deep slots)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+    for (int u = 0; u < ((A16_ABLATE & 4) ? 0 : 2); ++u) {
       const bf16x8 pb = pack8(s, u), db = pack8(dp, u);
       dv0 = mfmab(tr_frag(dOtr, TSTR, u, 0, lane), pb, dv0);
       dv1 = mfmab(tr_frag(dOtr, TSTR, u, 32, lane), pb, dv1);
       dk0 = mfmab(tr_frag(Qtr, TSTR, u, 0, lane), db, dk0);
       dk1 = mfmab(tr_frag(Qtr, TSTR, u, 32, lane), db, dk1);
     }
-    if (t + 1 < ntile) commit((t + 1) & 1);
-    if (t + 2 < ntile) prefetch(t + 2);
+    if (t + 1 < ntile) commit((t + 1) & 1, slot);
+    prefetch(t + 3, slot);
     __syncthreads();   // this tile's dS rows are in LDS, the next tile's images and statistics in place
+  };
+  for (int t = 0; t < ntile; t += 2) {
+    tile_step(t, 1);
+    if (t + 1 < ntile) tile_step(t + 1, 0);
   }
   dq_tile(ntile - 1);
   if (kvalid) {
@@ -415,7 +426,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
       bf16x4 a, c, d, e4;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        a[e] = (__bf16)dk0[4 * g + e]; c[e] = (__bf16)dk1[4 * g + e];
+        a[e] = (__bf16)(dk0[4 * g + e] * p.scale); c[e] = (__bf16)(dk1[4 * g + e] * p.scale);
         d[e] = (__bf16)dv0[4 * g + e]; e4[e] = (__bf16)dv1[4 * g + e];
       }
       *reinterpret_cast<bf16x4*>(kp + 8 * g) = a;
@@ -482,7 +493,7 @@ extern "C" int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, vo
 extern "C" int64_t amk_attn_bf16_bwd_ws_floats(int B, int H, int I, int J) {
   if (B <= 0 || H <= 0 || I <= 0 || J <= 0) return 0;
   const int64_t nkblk = (J + BKEYS - 1) / BKEYS;
-  return (int64_t)B * H * I + nkblk * B * I * H * 64;
+  return ((2 * (int64_t)B * H * I + 3) & ~3ll) + nkblk * B * I * H * 64;   // row constants {-(lse)/c2, -delta} + dQ partials
 }
 
 extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const float* stats, const void* d_o,
@@ -506,7 +517,7 @@ extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, co
   p.scale = scale; p.pinf = INFINITY;
   p.nkblk = (J + BKEYS - 1) / BKEYS;
   p.delta = ws;
-  p.dq_part = ws + (int64_t)B * H * I;
+  p.dq_part = ws + ((2 * (int64_t)B * H * I + 3) & ~3ll);
   AMK_CHECK_ARG(al16(q) && al16(k) && al16(v) && al16(o) && al16(d_o) && al16(dq) && al16(dk) && al16(dv) && al16(p.dq_part) &&
                     st_ok(p.qs) && st_ok(p.ks) && st_ok(p.vs) && st_ok(p.os) && st_ok(p.dos) && st_ok(p.dqs) && st_ok(p.dks) && st_ok(p.dvs),
                 "amk_attn_bf16_bwd: pointers must be 16-byte aligned and strides multiples of 8 elements");
@@ -518,7 +529,7 @@ extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, co
   hipLaunchKernelGGL(attn_bf16_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, p);
   const int64_t nwg = (int64_t)B * H * p.nkblk;
   AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_bf16_bwd: grid too large");
-  constexpr size_t lds = (size_t)(BKEYS * TSTR + 2 * BKEYS * DSTR + 4 * (32 * KSTR + 32 * TSTR)) * 2 + 2 * 96 * 4;
+  constexpr size_t lds = (size_t)(BKEYS * TSTR + 2 * BKEYS * DSTR + 4 * (32 * KSTR + 32 * TSTR)) * 2 + 2 * 64 * 4;
   static bool attr_set = false;
   if (!attr_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

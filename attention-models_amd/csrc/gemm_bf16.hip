@@ -198,6 +198,183 @@ __global__ __launch_bounds__(256) void tn_bf16_reduce_kernel(Params p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward and input gradient of nn.Linear in the mixed-precision mode: C = A W^T (+ bias) [NT: W (N, K) as stored] and
+// C = A W [NN: dX = dY W, W (K, N) as stored], A (M, K) and C (M, N) bf16, f32 accumulation, the bias (f32) added before
+// the one rounding.  EPI 1 (NT only): the SwiGLU gate folded in -- the tile holds 64 gate columns j and the matching 64
+// value columns H + j, and G[m, j] = silu(a) b leaves with (or instead of) the (a | b) tile.
+//   tile 128 x 128, four waves as 2 x 2 of 64 x 64, contraction in steps of 32, two tiles of the step stream in flight
+//   in registers beside the one in LDS, four workgroups per CU (K is 256 for most of these products: a tile is eight
+//   steps, so its prologue and epilogue are hidden by the CU's other workgroups, not by its own loop).
+//   The product is formed TRANSPOSED (W fragments as the MFMA's row operand), so a lane ends with four consecutive
+//   output columns of one row; the tile is then turned through LDS into 16-byte row pieces.
+constexpr int FSTR = 32;            // bf16 per LDS row of a [128 rows][32 k] operand tile: no padding, the four 16-byte
+                                    // chunks of row r sit at chunk ^ ((r >> 2) & 3) (writes and b128 reads conflict-free)
+constexpr int FT = 32 * STR;        // elements per operand tile buffer (the [32 k][128 n] tile of the NN form; >= 128 * FSTR)
+constexpr int OSTR = 136;           // bf16 per row of the output tile in LDS
+
+struct FParams {
+  const __bf16 *a, *w;
+  const float* bias;
+  __bf16 *c, *g;
+  int64_t M, lda, ldw, ldc, ldg;
+  int N, K, H, ntn, total;
+};
+
+template <bool BTR, int EPI>
+__global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
+  static_assert(FT >= 128 * FSTR, "the two B tile shapes share one buffer");
+  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 2 * FT];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
+  const int wn = wave & 1, wm = wave >> 1;
+  const int u = xcd_remap(blockIdx.x, p.total);
+  const int tm = u / p.ntn, tn = u - tm * p.ntn;   // neighbours share the A panel
+  const int64_t m0 = (int64_t)tm * 128;
+  const int n0 = EPI == 1 ? tn * 64 : tn * 128;    // (SwiGLU: first gate column)
+  // local output column (0..127) -> column of C; 8-column groups stay together
+  auto ncol = [&](int loc) {   // (>= N: not a column of this problem)
+    if (EPI != 1) return n0 + loc;
+    const int j = n0 + 32 * (loc >> 6) + (loc & 31);
+    return j < p.H ? ((loc >> 5) & 1) * p.H + j : p.N;
+  };
+  const int nk = (p.K + 31) / 32;
+  const int mrows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
+  // ---- staging
+  const int ar = tid >> 2, ach = tid & 3;          // A (and NT W): pieces (row ar + 64 i, 8 k at 8 ach)
+  const int cg = tid & 15, sr = tid >> 4;          // NN W: pieces (k row sr + 16 i, 8 columns at 8 cg)
+  const __amdgpu_buffer_rsrc_t a_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.a + m0 * p.lda), 0, (int)(((int64_t)(mrows - 1) * p.lda + p.K) * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)p.w, 0, (int)((BTR ? (int64_t)(p.K - 1) * p.ldw + p.N : (int64_t)(p.N - 1) * p.ldw + p.K) * 2), 0x00020000);
+  unsigned aoff[2], woff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    aoff[i] = (unsigned)(((int64_t)(ar + 64 * i) * p.lda + 8 * ach) * 2);
+    if (BTR) {
+      const int col = n0 + 8 * cg;
+      woff[i] = col < p.N ? (unsigned)(((int64_t)(sr + 16 * i) * p.ldw + col) * 2) : COL_PAST;
+    } else {
+      const int n = ncol(ar + 64 * i);
+      woff[i] = n < p.N ? (unsigned)(((int64_t)n * p.ldw + 8 * ach) * 2) : COL_PAST;
+    }
+  }
+  const unsigned wstep = BTR ? (unsigned)(32 * p.ldw * 2) : 64u;
+  struct Stg { float4 a[2], w[2]; };
+  auto gload = [&](Stg& g, int t) {
+    const int tt = t < nk ? t : nk - 1;
+    const bool kin = 32 * tt + 8 * ach < p.K;   // (K a multiple of 8: a piece is in or out)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      g.a[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(kin ? aoff[i] + (unsigned)tt * 64u : COL_PAST), 0, 0));
+      g.w[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)((BTR || kin) ? woff[i] + (unsigned)tt * wstep : COL_PAST), 0, 0));
+    }
+  };
+  auto lstore = [&](__bf16* stage, const Stg& g) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int sw = 8 * (ach ^ ((ar >> 2) & 3));   // (rows ar and ar + 64: the same swizzle)
+      *reinterpret_cast<float4*>(&stage[(ar + 64 * i) * FSTR + sw]) = g.a[i];
+      if (BTR) *reinterpret_cast<float4*>(&stage[FT + (sr + 16 * i) * STR + 8 * cg]) = g.w[i];
+      else *reinterpret_cast<float4*>(&stage[FT + (ar + 64 * i) * FSTR + sw]) = g.w[i];
+    }
+  };
+  f32x16 acc[2][2];   // [n block][m block]
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = zero16();
+  Stg ga, gb;
+  gload(ga, 0);
+  gload(gb, 1);
+  lstore(smem, ga);
+  gload(ga, 2);
+  __syncthreads();
+  auto step = [&](int t, Stg& g) {
+    const __bf16* cur = smem + (t & 1) * 2 * FT;
+    lstore(smem + ((t + 1) & 1) * 2 * FT, g);
+    gload(g, t + 3);
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      bf16x8 xf[2], wf[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int sw = 8 * ((2 * s + hf) ^ ((ln >> 2) & 3));   // (row offsets 64 w + 32 i: multiples of 16, swizzle of ln)
+        xf[i] = *reinterpret_cast<const bf16x8*>(&cur[(64 * wm + 32 * i + ln) * FSTR + sw]);
+        wf[i] = BTR ? tr_frag(cur + FT, 16 * s, 64 * wn + 32 * i, lane)
+                    : *reinterpret_cast<const bf16x8*>(&cur[FT + (64 * wn + 32 * i + ln) * FSTR + sw]);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  };
+  for (int t = 0; t < nk; t += 2) {
+    step(t, gb);
+    if (t + 1 < nk) step(t + 1, ga);
+  }
+  // ---- epilogue: acc[i][j][r] = C[m0 + 64 wm + 32 j + ln][ncol(64 wn + 32 i + (r & 3) + 8 (r >> 2) + 4 hf)]
+  if (p.bias) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int n = ncol(64 * wn + 32 * i + 8 * g + 4 * hf);
+        if (n < p.N) {
+          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+          for (int j = 0; j < 2; ++j) { acc[i][j][4 * g] += b4.x; acc[i][j][4 * g + 1] += b4.y; acc[i][j][4 * g + 2] += b4.z; acc[i][j][4 * g + 3] += b4.w; }
+        }
+      }
+  }
+  __bf16* ot = smem;   // [128][OSTR] (the loop ended with a barrier)
+  auto put_tile = [&](int nblocks) {   // the accumulators (n blocks 0..nblocks-1) as bf16 into the LDS tile
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (i >= nblocks) break;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          bf16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (__bf16)acc[i][j][4 * g + e];
+          const int loc = nblocks == 2 ? 64 * wn + 32 * i + 8 * g + 4 * hf : 32 * wn + 8 * g + 4 * hf;
+          *reinterpret_cast<bf16x4*>(&ot[(64 * wm + 32 * j + ln) * OSTR + loc]) = v;
+        }
+    }
+  };
+  if (EPI == 0 || p.c) {
+    put_tile(2);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int pc = tid + 256 * i, row = pc >> 4, loc = 8 * (pc & 15);
+      const int n = ncol(loc);
+      if (row < mrows && n < p.N) *reinterpret_cast<float4*>(p.c + (m0 + row) * p.ldc + n) = *reinterpret_cast<const float4*>(&ot[row * OSTR + loc]);
+    }
+  }
+  if (EPI == 1) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a = acc[0][j][r];
+        acc[0][j][r] = a * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-a * AMK_LOG2E)) * acc[1][j][r];
+      }
+    put_tile(1);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pc = tid + 256 * i, row = pc >> 3, loc = 8 * (pc & 7);
+      const int jcol = n0 + 32 * (loc >> 5) + (loc & 31);
+      if (row < mrows && jcol < p.H) *reinterpret_cast<float4*>(p.g + (m0 + row) * p.ldg + jcol) = *reinterpret_cast<const float4*>(&ot[row * OSTR + loc]);
+    }
+  }
+}
+
 }  // namespace amk_gemm16
 
 using namespace amk_gemm16;
@@ -275,5 +452,35 @@ extern "C" int amk_gemm_tn_bf16(const void* y, int64_t ldy, const void* x, int64
     hipLaunchKernelGGL(tn_bf16_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
   }
   AMK_CHECK_LAUNCH("amk_gemm_tn_bf16");
+  return AMK_OK;
+}
+
+
+// op 0: c = a w^T (+ bias), w (N, K); op 1: c = a w, w (K, N); epi 1 (op 0 only): w = (gate rows | value rows) (2 H, K),
+// g (M, H) = silu(a w_gate^T + b_gate) * (a w_value^T + b_value), c (M, 2 H) optional
+extern "C" int amk_gemm_bf16(int op, int epi, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                             void* c, int64_t ldc, void* g, int64_t ldg, int64_t M, int N, int K, void* stream) {
+  AMK_CHECK_ARG(a && w, "amk_gemm_bf16: null operand");
+  AMK_CHECK_ARG((op == 0 || op == 1) && (epi == 0 || (epi == 1 && op == 0)), "amk_gemm_bf16: unknown op %d / epilogue %d", op, epi);
+  AMK_CHECK_ARG(epi == 1 ? g != nullptr : c != nullptr, "amk_gemm_bf16: null output");
+  AMK_CHECK_ARG(M > 0 && N > 0 && K > 0, "amk_gemm_bf16: non-positive size");
+  AMK_CHECK_SUPPORTED(N % 8 == 0 && K % 8 == 0 && lda % 8 == 0 && ldw % 8 == 0 && (!c || ldc % 8 == 0) && (epi == 0 || (ldg % 8 == 0 && N % 16 == 0)),
+                      "amk_gemm_bf16: N, K and the leading dimensions must be multiples of 8 (N of 16 with the SwiGLU epilogue)");
+  AMK_CHECK_ARG(((uintptr_t)a & 15) == 0 && ((uintptr_t)w & 15) == 0 && ((uintptr_t)c & 15) == 0 && ((uintptr_t)g & 15) == 0 && ((uintptr_t)bias & 15) == 0,
+                "amk_gemm_bf16: pointers must be 16-byte aligned");
+  AMK_CHECK_SUPPORTED(128 * lda * 2 < (1ll << 30) && (op == 1 ? (int64_t)K * ldw : (int64_t)N * ldw) * 2 < (1ll << 30), "amk_gemm_bf16: operand panel beyond 1 GiB");
+  FParams p = {};
+  p.a = static_cast<const __bf16*>(a); p.w = static_cast<const __bf16*>(w); p.bias = bias;
+  p.c = static_cast<__bf16*>(c); p.g = static_cast<__bf16*>(g);
+  p.M = M; p.N = N; p.K = K; p.lda = lda; p.ldw = ldw; p.ldc = ldc; p.ldg = ldg; p.H = N / 2;
+  p.ntn = epi == 1 ? (p.H + 63) / 64 : (N + 127) / 128;
+  const int64_t total = ((M + 127) / 128) * p.ntn;
+  AMK_CHECK_SUPPORTED(total < (1ll << 31), "amk_gemm_bf16: grid too large");
+  p.total = (int)total;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (op == 1) hipLaunchKernelGGL((gemm_bf16_kernel<true, 0>), dim3((unsigned)total), dim3(256), 0, st, p);
+  else if (epi == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, 1>), dim3((unsigned)total), dim3(256), 0, st, p);
+  else hipLaunchKernelGGL((gemm_bf16_kernel<false, 0>), dim3((unsigned)total), dim3(256), 0, st, p);
+  AMK_CHECK_LAUNCH("amk_gemm_bf16");
   return AMK_OK;
 }

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 131 /* 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
+#define AMK_VERSION 132 /* 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
 
 enum {
   AMK_OK = 0,
@@ -526,6 +526,15 @@ int amk_add_layernorm_mixed_bwd(const void* dy, int dy_is_bf16, const float* h, 
 int64_t amk_gemm_tn_bf16_ws_bytes(int64_t M, int N, int K);
 int amk_gemm_tn_bf16(const void* y, int64_t ldy, const void* x, int64_t ldx, float* c, int64_t ldc, float* dbias,
                      int64_t M, int N, int K, void* workspace, int64_t ws_bytes, void* stream);
+
+/* Forward and input gradient of nn.Linear in the mixed-precision mode (csrc/gemm_bf16.hip), bf16 in and out, f32
+ * accumulation, the f32 bias added before the one rounding:
+ *   op 0: c (M, N) = a (M, K) w^T + bias, w (N, K) as nn.Linear stores it;   op 1: c (M, N) = a (M, K) w, w (K, N) (dX = dY W)
+ *   epi 1 (op 0): the SwiGLU gate of models/vitvqgan.py:20-34 folded in: w = w12 (2 H, K), g (M, H) = silu(a-half) * b-half,
+ *   c (M, 2 H) optional (NULL: the pre-activations are not written).
+ * N, K and the leading dimensions multiples of 8 (N of 16 with epi 1); pointers 16-byte aligned; bias may be NULL. */
+int amk_gemm_bf16(int op, int epi, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
+                  void* c, int64_t ldc, void* g, int64_t ldg, int64_t M, int N, int K, void* stream);
 
 #ifdef __cplusplus
 }

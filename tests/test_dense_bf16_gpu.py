@@ -84,3 +84,87 @@ def test_linear_under_autocast(device, shape, N, bias):
     assert rel_err(ref[1], g16.t() @ x16) < 1e-2
     if bias:
         assert got[2].dtype == torch.float32 and rel_err(got[2], g16.sum(0)) < TOL
+
+
+FWD_SHAPES = [(1, 8, 8), (5, 16, 40), (130, 136, 24), (257, 304, 72), (1000, 192, 256), (333, 264, 1368), (4096, 2736, 256),
+              (2048, 32, 512), (128, 128, 32)]
+TOL16 = 2 ** -8   # one bf16 rounding of the output (2^-9 relative to each element, here relative to the largest)
+
+
+@pytest.mark.parametrize("M,N,K", FWD_SHAPES)
+@pytest.mark.parametrize("bias", [False, True])
+def test_nt_bf16(device, M, N, K, bias):
+    from amk import dense
+
+    a, w = seeded((M, K), 1 + K).bfloat16(), (seeded((N, K), 2 + N) * K ** -0.5).bfloat16()
+    b = seeded((N,), 3) if bias else None
+    ref = a.double() @ w.double().t() + (b.double() if bias else 0.0)
+    out = dense.gemm_nt_bf16(a.to(device), w.to(device), b.to(device) if bias else None)
+    assert out.dtype == torch.bfloat16 and out.shape == (M, N)
+    assert rel_err(out.float(), ref) < TOL16
+    # exactly the correctly rounded result wherever the fp32 sum is not at a rounding boundary
+    exact = (out.cpu() == ref.float().bfloat16()).float().mean().item()
+    assert exact > 0.99
+
+
+@pytest.mark.parametrize("M,N,K", FWD_SHAPES)
+def test_nn_bf16(device, M, N, K):
+    from amk import dense
+
+    a, w = seeded((M, K), 1 + K).bfloat16(), (seeded((K, N), 2 + N) * K ** -0.5).bfloat16()
+    ref = a.double() @ w.double()
+    out = dense.gemm_nn_bf16(a.to(device), w.to(device))
+    assert rel_err(out.float(), ref) < TOL16
+    assert (out.cpu() == ref.float().bfloat16()).float().mean().item() > 0.99
+
+
+@pytest.mark.parametrize("M,H,K", [(100, 64, 32), (300, 104, 40), (1000, 1368, 256), (129, 40, 256), (4096, 8, 64)])
+@pytest.mark.parametrize("keep", [True, False])
+def test_nt_swiglu_bf16(device, M, H, K, keep):
+    import torch.nn.functional as F
+
+    from amk import dense
+
+    a, w12, b12 = seeded((M, K), 1).bfloat16(), (seeded((2 * H, K), 2) * K ** -0.5).bfloat16(), seeded((2 * H,), 3)
+    ab_ref = a.double() @ w12.double().t() + b12.double()
+    g_ref = F.silu(ab_ref[:, :H]) * ab_ref[:, H:]
+    g, ab = dense.gemm_nt_swiglu_bf16(a.to(device), w12.to(device), b12.to(device), keep_ab=keep)
+    assert g.shape == (M, H) and rel_err(g.float(), g_ref) < TOL16
+    if keep:
+        assert rel_err(ab.float(), ab_ref) < TOL16
+    else:
+        assert ab is None
+
+
+def test_swiglu_ffn_under_autocast(device):
+    """ops.swiglu_ffn under bf16 autocast against the separate autocast ops (F.linear, silu * value, F.linear): bf16-level
+    agreement of the output and every gradient; weight / bias gradients in fp32."""
+    import torch.nn.functional as F
+
+    from amk import ops
+
+    D, H = 256, 1368
+    x = seeded((4, 200, D), 1).to(device).requires_grad_(True)
+    w12 = (seeded((2 * H, D), 2) * D ** -0.5).to(device).requires_grad_(True)
+    b12 = (seeded((2 * H,), 3) * 0.1).to(device).requires_grad_(True)
+    w3 = (seeded((D, H), 4) * H ** -0.5).to(device).requires_grad_(True)
+    b3 = (seeded((D,), 5) * 0.1).to(device).requires_grad_(True)
+    g = seeded((4, 200, D), 6).to(device).bfloat16()
+    ins = (x, w12, b12, w3, b3)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ops.swiglu_ffn(x, w12, b12, w3, b3)
+        ab = F.linear(x, w12, b12)
+        a, b = ab.chunk(2, dim=-1)
+        y_ref = F.linear(F.silu(a) * b, w3, b3)
+    assert y.dtype == torch.bfloat16
+    assert rel_err(y.float(), y_ref.float()) < 2e-2
+    got, ref = torch.autograd.grad(y, ins, g), torch.autograd.grad(y_ref, ins, g)
+    # fp64 gradients of the fp32 module as the yardstick for both
+    xd, w12d, b12d, w3d, b3d = (t.detach().double().requires_grad_(True) for t in ins)
+    abd = F.linear(xd, w12d, b12d)
+    ad, bd = abd.chunk(2, dim=-1)
+    exact = torch.autograd.grad(F.linear(F.silu(ad) * bd, w3d, b3d), (xd, w12d, b12d, w3d, b3d), g.double())
+    for name, u, v, e in zip(("dx", "dw12", "db12", "dw3", "db3"), got, ref, exact):
+        assert u.dtype == torch.float32 and u.shape == v.shape
+        assert rel_err(u, e) < 2e-2, name
+        assert rel_err(u, e) < 1.5 * rel_err(v.float(), e) + 1e-3, f"{name}: no worse than the library path"

@@ -18,6 +18,7 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--no-f32", action="store_true", help="skip the exact-f32 kernels' line")
     a = ap.parse_args()
     from amk import ops
 
@@ -35,6 +36,8 @@ if __name__ == "__main__":
     print(f"bf16 attention B{B} h{H} T{T} d{D}: forward {t_f*1e6:.1f} us = {core/t_f/1e12:.1f} TFLOP/s ({core/t_f/1e12/BF16_PEAK:.3f} of bf16 peak); "
           f"backward (delta + fused + dq reduce) {t_b*1e6:.1f} us = {2.5*core/t_b/1e12:.1f} TFLOP/s on its five products "
           f"({2.5*core/t_b/1e12/BF16_PEAK:.3f})")
+    if a.no_f32:
+        sys.exit(0)
     qf, kvf = q2.detach().float().requires_grad_(True), kv2.detach().float().requires_grad_(True)
     t_f32 = time_launches(lambda: ops.attention_fused_kv(qf, kvf, H, D, D ** -0.5), a.iters)
     t_fb32 = time_launches(lambda: torch.autograd.grad(ops.attention_fused_kv(qf, kvf, H, D, D ** -0.5), [qf, kvf], cot.float()), a.iters)
