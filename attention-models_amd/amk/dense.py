@@ -259,3 +259,17 @@ def gemm_nt_swiglu_bf16(a, w12, b12=None, keep_ab=True):
         rc = _lib.load().amk_gemm_bf16(0, 1, _p(a), a.stride(0), _p(w12), w12.stride(0), _p(b12), _p(ab), N, _p(g), N // 2, M, N, K, _stream())
         _lib.check(rc, "amk_gemm_bf16")
     return g, ab
+
+
+def gemm_nn_swiglu_bwd_bf16(dy, w3, ab):
+    """(dA | dB) (M, 2 H) for dG = dy (M, K) w3 (K, H) and the forward's ab = (a | b) (M, 2 H), one launch."""
+    dy, w3, ab = _mat16(dy, "dy"), _mat16(w3, "w3"), _mat16(ab, "ab")
+    (M, K), H = dy.shape, w3.shape[1]
+    if w3.shape[0] != K or ab.shape != (M, 2 * H) or not supported_bf16(H, K):
+        raise RuntimeError(f"gemm_nn_swiglu_bwd_bf16: dy {tuple(dy.shape)}, w3 {tuple(w3.shape)}, ab {tuple(ab.shape)}")
+    dab = torch.empty(M, 2 * H, device=dy.device, dtype=torch.bfloat16)
+    if M:
+        rc = _lib.load().amk_gemm_bf16_swiglu_bwd(_p(dy), dy.stride(0), _p(w3), w3.stride(0), _p(ab), ab.stride(0), _p(dab), 2 * H,
+                                                  M, H, K, _stream())
+        _lib.check(rc, "amk_gemm_bf16_swiglu_bwd")
+    return dab

@@ -70,6 +70,7 @@ SIGNATURES = {
     "amk_opt_num_partials": (_I, []),
     "amk_sumsq_partials": (_I, [_P, _L, _P, _P]),
     "amk_adam_flat_step": (_I, [_P] * 4 + [_L, _P, _P, _P, _I] + [_F] * 6 + [_I, _P, _P]),
+    "amk_adam_flat_step_shadow": (_I, [_P] * 4 + [_L, _P, _P, _P, _I] + [_F] * 6 + [_I, _P, _P, _P]),
     "amk_gemm_x6_planes_bytes": (_L, [_I, _I]),
     "amk_gemm_x6_split": (_I, [_P, _L, _I, _I, _P, _P]),
     "amk_gemm_x6_nt": (_I, [_P, _L, _P, _P, _P, _L, _I, _I, _I, _P]),
@@ -84,6 +85,7 @@ SIGNATURES = {
     "amk_add_layernorm_mixed_fwd": (_I, [_P, _I, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
     "amk_add_layernorm_mixed_bwd": (_I, [_P, _I, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "amk_gemm_bf16": (_I, [_I, _I, _P, _L, _P, _L, _P, _P, _L, _P, _L, _L, _I, _I, _P]),
+    "amk_gemm_bf16_swiglu_bwd": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _L, _I, _I, _P]),
     "amk_gemm_tn_bf16_ws_bytes": (_L, [_L, _I, _I]),
     "amk_gemm_tn_bf16": (_I, [_P, _L, _P, _L, _P, _L, _P, _L, _I, _I, _P, _L, _P]),
     "amk_sample_step": (_I, [_P, _P, _F, _P, _c.c_uint64, _c.c_uint64, _F, _L, _I, _I, _P, _F, _P, _P, _P]),

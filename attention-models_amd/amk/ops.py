@@ -1180,6 +1180,14 @@ class _SwiGLUFFN(torch.autograd.Function):
 MIXED_WGRAD = os.environ.get("AMK_MIXED_WGRAD", "1") == "1"
 
 
+def _w16(t):
+    """The bf16 copy of a parameter: the one FlatAdam(bf16_shadow=True) keeps current, else a cast."""
+    if t is None:
+        return None
+    shadow = getattr(t, "_amk_bf16", None)
+    return shadow if shadow is not None else t.to(torch.bfloat16)
+
+
 class _LinearMixed(torch.autograd.Function):
     """nn.Linear under bf16 autocast: forward and input gradient by the library's bf16 GEMMs as autocast runs them,
     weight and bias gradient by amk_gemm_tn_bf16 -- one pass over dY and X, f32 results (csrc/gemm_bf16.hip; the library
@@ -1187,10 +1195,10 @@ class _LinearMixed(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        x16, w16 = x.to(torch.bfloat16), weight.to(torch.bfloat16)
+        x16, w16 = x.to(torch.bfloat16), _w16(weight)
         ctx.save_for_backward(x16, w16)
         ctx.has_bias, ctx.x_dtype = bias is not None, x.dtype
-        return torch.nn.functional.linear(x16, w16, None if bias is None else bias.to(torch.bfloat16))
+        return torch.nn.functional.linear(x16, w16, _w16(bias))
 
     @staticmethod
     def backward(ctx, dy):
@@ -1241,9 +1249,9 @@ class _SwiGLUFFNMixed(torch.autograd.Function):
         from . import dense
 
         x16 = x.to(torch.bfloat16).reshape(-1, x.shape[-1])
-        w12h, w3h = w12.to(torch.bfloat16), w3.to(torch.bfloat16)
+        w12h, w3h = _w16(w12), _w16(w3)
         g, ab = dense.gemm_nt_swiglu_bf16(x16, w12h, b12)
-        y = torch.nn.functional.linear(g, w3h, None if b3 is None else b3.to(torch.bfloat16))
+        y = torch.nn.functional.linear(g, w3h, _w16(b3))
         ctx.save_for_backward(x16, ab, g, w12h, w3h)
         ctx.x_shape, ctx.x_dtype, ctx.bias = x.shape, x.dtype, (b12 is not None, b3 is not None)
         return y.view(*x.shape[:-1], w3.shape[0])
@@ -1255,10 +1263,7 @@ class _SwiGLUFFNMixed(torch.autograd.Function):
         x16, ab, g, w12h, w3h = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
         dw3, db3 = dense.gemm_tn_bf16(dy2, g, want_bias=ctx.bias[1])
-        dg = dense.gemm_nn_bf16(dy2, w3h)
-        dab = torch.empty_like(ab)
-        M, H2 = ab.shape
-        _lib.check(_lib.load().amk_swiglu_bf16_bwd(_ptr(ab), _ptr(dg), M, H2 // 2, _ptr(dab), _stream()), "amk_swiglu_bf16_bwd")
+        dab = dense.gemm_nn_swiglu_bwd_bf16(dy2, w3h, ab)   # dY W3 with the gate's backward in its epilogue
         dw12, db12 = dense.gemm_tn_bf16(dab, x16, want_bias=ctx.bias[0])
         dx = dab.mm(w12h).view(ctx.x_shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         return dx, dw12, db12, dw3, db3
@@ -1266,10 +1271,16 @@ class _SwiGLUFFNMixed(torch.autograd.Function):
 
 def swiglu_ffn(x, w12, b12, w3, b3):
     """w3(silu(a) * b), (a | b) = w12(x): fused (see _SwiGLUFFN) when the shapes allow, else the separate launches."""
-    if (torch.is_autocast_enabled() and _mixed_linear_ok(x, w12) and _mixed_linear_ok(x, w3) and w3.requires_grad
-            and w12.shape[0] % 16 == 0 and w12.shape[0] >= 1024):
-        with torch.autocast("cuda", enabled=False):
-            return _SwiGLUFFNMixed.apply(x, w12, b12, w3, b3)
+    if torch.is_autocast_enabled() and w12.shape[0] % 16 == 0 and w12.shape[0] >= 1024:
+        if _mixed_linear_ok(x, w12) and _mixed_linear_ok(x, w3) and w3.requires_grad:
+            with torch.autocast("cuda", enabled=False):
+                return _SwiGLUFFNMixed.apply(x, w12, b12, w3, b3)
+        if (MIXED_WGRAD and not torch.is_grad_enabled() and x.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16
+                and w12.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16) and w12.shape[1] % 8 == 0 and x.numel()):
+            from . import dense   # inference: the gate only, the pre-activations never reach HBM
+
+            g, _ = dense.gemm_nt_swiglu_bf16(x.to(torch.bfloat16).reshape(-1, x.shape[-1]), _w16(w12), b12, keep_ab=False)
+            return torch.nn.functional.linear(g, _w16(w3), _w16(b3)).view(*x.shape[:-1], w3.shape[0])
     if GEMM_MODE != "bf16x6" and _dense_ok(x, w12) and w3.shape[1] % 4 == 0 and w3.shape[0] % 4 == 0 and w3.is_contiguous():
         return _SwiGLUFFN.apply(x, w12, b12, w3, b3)
     ab = linear(x, w12, b12)

@@ -23,11 +23,16 @@ def _ptr(t):
 
 class FlatAdam:
     def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
-                 capturable=False):
+                 capturable=False, bf16_shadow=False):
         """capturable=True: the per-parameter table {active, lr / bias-correction-1, sqrt(bias-correction-2)} is
         computed on the device from device-resident step counts and learning rate (a few tiny launches) instead of on
         the host, so that ``step`` can be captured into a HIP graph and replayed (amk/graphs.py): nothing in it then
-        reads host memory.  The set of parameters that receive gradients must not change between replays."""
+        reads host memory.  The set of parameters that receive gradients must not change between replays.
+
+        bf16_shadow=True: a bf16 copy of every parameter (``p._amk_bf16``, a view of one flat buffer per bucket) is kept
+        current by the update kernel itself; the mixed-precision ops (amk.ops.linear / swiglu_ffn under bf16 autocast)
+        read it instead of casting the fp32 weight on every call.  Code that writes parameters behind the optimizer's
+        back (load_state_dict, manual init) must call ``refresh_shadow()``."""
         if not reducer.on_gpu:
             raise RuntimeError("FlatAdam runs on MI355X (HIP) parameters only; use torch.optim on CPU")
         if capturable and decoupled and weight_decay:
@@ -41,7 +46,7 @@ class FlatAdam:
         dev = reducer.buckets[0].flat.device
         self.params = [p for b in reducer.buckets for p in b.params]
         self.steps = np.zeros(len(self.params), dtype=np.int64)
-        self.flat_p, self.m, self.v, self.seg = [], [], [], []
+        self.flat_p, self.m, self.v, self.seg, self.flat_p16 = [], [], [], [], []
         pid = 0
         for b in reducer.buckets:
             fp = torch.zeros_like(b.flat)
@@ -54,6 +59,11 @@ class FlatAdam:
                 seg[off // ALIGN: off // ALIGN + nseg] = pid
                 pid += 1
             self.flat_p.append(fp)
+            if bf16_shadow:
+                f16 = fp.to(torch.bfloat16)
+                for p, off in zip(b.params, b.offsets):
+                    p._amk_bf16 = f16[off:off + p.numel()].view_as(p)
+                self.flat_p16.append(f16)
             self.m.append(torch.zeros_like(b.flat))
             self.v.append(torch.zeros_like(b.flat))
             self.seg.append(seg.to(dev))
@@ -69,6 +79,11 @@ class FlatAdam:
             self.steps_dev = torch.zeros(len(self.params), device=dev, dtype=torch.float64)
             self.lr_dev = torch.full((), float(lr), device=dev, dtype=torch.float64)
             self._fired_host, self._fired_dev = None, None
+
+    def refresh_shadow(self):
+        """Re-derive the bf16 copies from the fp32 parameters (after anything but ``step`` wrote them)."""
+        for fp, f16 in zip(self.flat_p, self.flat_p16):
+            f16.copy_(fp)
 
     @property
     def lr(self):
@@ -128,11 +143,12 @@ class FlatAdam:
             _lib.check(L.amk_sumsq_partials(_ptr(b.flat), b.flat.numel(), _ptr(self.partials[k * self.npart:]), stream),
                        "amk_sumsq_partials")
         for k, b in enumerate(red.buckets):
-            rc = L.amk_adam_flat_step(
+            rc = L.amk_adam_flat_step_shadow(
                 _ptr(self.flat_p[k]), _ptr(b.flat), _ptr(self.m[k]), _ptr(self.v[k]), b.flat.numel(),
                 _ptr(self.seg[k]), _ptr(tab_d), _ptr(self.partials), self.partials.numel(),
                 clip, float(self.lr), float(b1), float(b2), float(self.eps), float(self.weight_decay),
-                1 if self.decoupled else 0, _ptr(self.norm) if k == 0 else _ptr(None), stream)
+                1 if self.decoupled else 0, _ptr(self.norm) if k == 0 else _ptr(None),
+                _ptr(self.flat_p16[k]) if self.flat_p16 else _ptr(None), stream)
             _lib.check(rc, "amk_adam_flat_step")
         red.mark_zeroed()
         return self.norm

@@ -64,7 +64,9 @@ class VQGANTrainStep:
         okw = dict(betas=betas, weight_decay=weight_decay, fused=fused)
         self._graph = None
         if self.fused_optimizer:
-            self.g_optim = FlatAdam(self.g_red, lr=lr, betas=betas, weight_decay=weight_decay, capturable=capturable)
+            # under bf16 autocast the generator's update kernel also refreshes the bf16 copies its GEMMs read
+            self.g_optim = FlatAdam(self.g_red, lr=lr, betas=betas, weight_decay=weight_decay, capturable=capturable,
+                                    bf16_shadow=autocast == torch.bfloat16)
             self.d_optim = FlatAdam(self.d_red, lr=lr, betas=betas, weight_decay=weight_decay, capturable=capturable)
         elif capturable:
             dev = next(model.parameters()).device

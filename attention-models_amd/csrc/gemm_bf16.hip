@@ -203,7 +203,9 @@ __global__ __launch_bounds__(256) void tn_bf16_reduce_kernel(Params p) {
 // Forward and input gradient of nn.Linear in the mixed-precision mode: C = A W^T (+ bias) [NT: W (N, K) as stored] and
 // C = A W [NN: dX = dY W, W (K, N) as stored], A (M, K) and C (M, N) bf16, f32 accumulation, the bias (f32) added before
 // the one rounding.  EPI 1 (NT only): the SwiGLU gate folded in -- the tile holds 64 gate columns j and the matching 64
-// value columns H + j, and G[m, j] = silu(a) b leaves with (or instead of) the (a | b) tile.
+// value columns H + j, and G[m, j] = silu(a) b leaves with (or instead of) the (a | b) tile.  EPI 2 (NN only): the
+// gate's backward folded in -- the product is dG (M, H), and what leaves is (dA | dB) (M, 2 H) from the forward's (a | b):
+// dG is rounded to bf16 as the unfused pair of launches would hand it over, then combined in the row pass.
 //   tile 128 x 128, four waves as 2 x 2 of 64 x 64, contraction in steps of 32, two tiles of the step stream in flight
 //   in registers beside the one in LDS, four workgroups per CU (K is 256 for most of these products: a tile is eight
 //   steps, so its prologue and epilogue are hidden by the CU's other workgroups, not by its own loop).
@@ -215,10 +217,10 @@ constexpr int FT = 32 * STR;        // elements per operand tile buffer (the [32
 constexpr int OSTR = 136;           // bf16 per row of the output tile in LDS
 
 struct FParams {
-  const __bf16 *a, *w;
+  const __bf16 *a, *w, *ab;
   const float* bias;
   __bf16 *c, *g;
-  int64_t M, lda, ldw, ldc, ldg;
+  int64_t M, lda, ldw, ldc, ldg, ldab;
   int N, K, H, ntn, total;
 };
 
@@ -345,7 +347,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
         }
     }
   };
-  if (EPI == 0 || p.c) {
+  if (EPI == 0 || (EPI == 1 && p.c)) {
     put_tile(2);
     __syncthreads();
 #pragma unroll
@@ -353,6 +355,30 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
       const int pc = tid + 256 * i, row = pc >> 4, loc = 8 * (pc & 15);
       const int n = ncol(loc);
       if (row < mrows && n < p.N) *reinterpret_cast<float4*>(p.c + (m0 + row) * p.ldc + n) = *reinterpret_cast<const float4*>(&ot[row * OSTR + loc]);
+    }
+  }
+  if (EPI == 2) {
+    put_tile(2);
+    __syncthreads();
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+      const int pc = tid + 256 * i, row = pc >> 4, loc = 8 * (pc & 15);
+      const int j = n0 + loc;
+      if (row < mrows && j < p.N) {
+        const bf16x8 dg = *reinterpret_cast<const bf16x8*>(&ot[row * OSTR + loc]);
+        const bf16x8 av = *reinterpret_cast<const bf16x8*>(p.ab + (m0 + row) * p.ldab + j);
+        const bf16x8 bv = *reinterpret_cast<const bf16x8*>(p.ab + (m0 + row) * p.ldab + p.N + j);
+        bf16x8 da, db;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = (float)av[e], g = (float)dg[e];
+          const float sg = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-a * AMK_LOG2E));
+          da[e] = (__bf16)(g * (float)bv[e] * (sg * (1.f + a * (1.f - sg))));
+          db[e] = (__bf16)(g * (a * sg));
+        }
+        *reinterpret_cast<bf16x8*>(p.c + (m0 + row) * p.ldc + j) = da;
+        *reinterpret_cast<bf16x8*>(p.c + (m0 + row) * p.ldc + p.N + j) = db;
+      }
     }
   }
   if (EPI == 1) {
@@ -482,5 +508,30 @@ extern "C" int amk_gemm_bf16(int op, int epi, const void* a, int64_t lda, const 
   else if (epi == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false, 1>), dim3((unsigned)total), dim3(256), 0, st, p);
   else hipLaunchKernelGGL((gemm_bf16_kernel<false, 0>), dim3((unsigned)total), dim3(256), 0, st, p);
   AMK_CHECK_LAUNCH("amk_gemm_bf16");
+  return AMK_OK;
+}
+
+
+// (dA | dB) (M, 2 H) = SwiGLU backward of dG = dy (M, K) w3 (K, H), with the forward's (a | b) (M, 2 H): the input gradient
+// of the FFN's second projection and the gate's backward in one launch (dG never reaches HBM)
+extern "C" int amk_gemm_bf16_swiglu_bwd(const void* dy, int64_t lddy, const void* w3, int64_t ldw, const void* ab, int64_t ldab,
+                                        void* dab, int64_t lddab, int64_t M, int H, int K, void* stream) {
+  AMK_CHECK_ARG(dy && w3 && ab && dab, "amk_gemm_bf16_swiglu_bwd: null operand");
+  AMK_CHECK_ARG(M > 0 && H > 0 && K > 0, "amk_gemm_bf16_swiglu_bwd: non-positive size");
+  AMK_CHECK_SUPPORTED(H % 8 == 0 && K % 8 == 0 && lddy % 8 == 0 && ldw % 8 == 0 && ldab % 8 == 0 && lddab % 8 == 0,
+                      "amk_gemm_bf16_swiglu_bwd: H, K and the leading dimensions must be multiples of 8");
+  AMK_CHECK_ARG(((uintptr_t)dy & 15) == 0 && ((uintptr_t)w3 & 15) == 0 && ((uintptr_t)ab & 15) == 0 && ((uintptr_t)dab & 15) == 0,
+                "amk_gemm_bf16_swiglu_bwd: pointers must be 16-byte aligned");
+  AMK_CHECK_SUPPORTED(128 * lddy * 2 < (1ll << 30) && (int64_t)K * ldw * 2 < (1ll << 30), "amk_gemm_bf16_swiglu_bwd: operand panel beyond 1 GiB");
+  FParams p = {};
+  p.a = static_cast<const __bf16*>(dy); p.w = static_cast<const __bf16*>(w3); p.ab = static_cast<const __bf16*>(ab);
+  p.c = static_cast<__bf16*>(dab);
+  p.M = M; p.N = H; p.K = K; p.lda = lddy; p.ldw = ldw; p.ldc = lddab; p.ldab = ldab; p.H = H;
+  p.ntn = (H + 127) / 128;
+  const int64_t total = ((M + 127) / 128) * p.ntn;
+  AMK_CHECK_SUPPORTED(total < (1ll << 31), "amk_gemm_bf16_swiglu_bwd: grid too large");
+  p.total = (int)total;
+  hipLaunchKernelGGL((gemm_bf16_kernel<true, 2>), dim3((unsigned)total), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  AMK_CHECK_LAUNCH("amk_gemm_bf16_swiglu_bwd");
   return AMK_OK;
 }

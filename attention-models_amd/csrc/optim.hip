@@ -56,6 +56,7 @@ struct AdamArgs {
   float max_norm, beta1, beta2, eps, weight_decay, lr;
   int decoupled;             // 0: Adam (L2 term added to the gradient), 1: AdamW
   float* norm_out;           // (1) the global gradient norm before clipping, or null
+  __bf16* p16;               // bf16 copy of the parameters for the mixed-precision GEMMs, refreshed here, or null
 };
 
 __global__ __launch_bounds__(256) void adam_flat_kernel(AdamArgs a) {
@@ -100,6 +101,12 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(AdamArgs a) {
     AMK_ADAM_ONE(x) AMK_ADAM_ONE(y) AMK_ADAM_ONE(z) AMK_ADAM_ONE(w)
 #undef AMK_ADAM_ONE
     st4(a.p + off, p);
+    if (a.p16) {
+      typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+      bf16x4 h;
+      h[0] = (__bf16)p.x; h[1] = (__bf16)p.y; h[2] = (__bf16)p.z; h[3] = (__bf16)p.w;
+      *reinterpret_cast<bf16x4*>(a.p16 + off) = h;
+    }
     st4(a.m + off, m);
     st4(a.v + off, v);
   }
@@ -122,11 +129,11 @@ extern "C" int amk_sumsq_partials(const float* x, int64_t n, float* partials, vo
   return AMK_OK;
 }
 
-extern "C" int amk_adam_flat_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                                  const int32_t* seg_param, const float* param_tab,
-                                  const float* partials, int n_partials,
-                                  float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
-                                  int decoupled, float* norm_out, void* stream) {
+extern "C" int amk_adam_flat_step_shadow(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                         const int32_t* seg_param, const float* param_tab,
+                                         const float* partials, int n_partials,
+                                         float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                         int decoupled, float* norm_out, void* param_bf16, void* stream) {
   AMK_CHECK_ARG(param && grad && exp_avg && exp_avg_sq && seg_param && param_tab, "amk_adam_flat_step: null pointer");
   AMK_CHECK_ARG(n > 0 && n % SEG == 0, "amk_adam_flat_step: n = %lld must be a positive multiple of %d", (long long)n, SEG);
   AMK_CHECK_ARG(max_norm <= 0.f || (partials && n_partials > 0), "amk_adam_flat_step: clipping needs the norm partials");
@@ -140,9 +147,20 @@ extern "C" int amk_adam_flat_step(float* param, float* grad, float* exp_avg, flo
   a.max_norm = max_norm; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.weight_decay = weight_decay; a.lr = lr;
   a.decoupled = decoupled;
   a.norm_out = norm_out;
+  a.p16 = static_cast<__bf16*>(param_bf16);
+  AMK_CHECK_ARG((reinterpret_cast<uintptr_t>(param_bf16) & 7) == 0, "amk_adam_flat_step: the bf16 copy must be 8-byte aligned");
   const int64_t nwg = (a.nseg + 3) / 4;
   const unsigned grid = (unsigned)(nwg < 2048 ? nwg : 2048);
   hipLaunchKernelGGL(adam_flat_kernel, dim3(grid), dim3(256), 0, static_cast<hipStream_t>(stream), a);
   AMK_CHECK_LAUNCH("amk_adam_flat_step");
   return AMK_OK;
+}
+
+extern "C" int amk_adam_flat_step(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                  const int32_t* seg_param, const float* param_tab,
+                                  const float* partials, int n_partials,
+                                  float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                                  int decoupled, float* norm_out, void* stream) {
+  return amk_adam_flat_step_shadow(param, grad, exp_avg, exp_avg_sq, n, seg_param, param_tab, partials, n_partials, max_norm, lr, beta1,
+                                   beta2, eps, weight_decay, decoupled, norm_out, nullptr, stream);
 }

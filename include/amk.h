@@ -386,6 +386,14 @@ int amk_adam_flat_step(float* param, float* grad, float* exp_avg, float* exp_avg
                        const float* partials, int n_partials,
                        float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
                        int decoupled, float* norm_out, void* stream);
+/* The same step, also refreshing param_bf16 (n bf16 values, 8-byte aligned; NULL: none): the copy of the parameters the
+ * mixed-precision GEMMs read, so that torch.autocast's per-call weight casts (accelerator.autocast, trainers/
+ * vitgqgan.py:139-190) have nothing left to do. */
+int amk_adam_flat_step_shadow(float* param, float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                              const int32_t* seg_param, const float* param_tab,
+                              const float* partials, int n_partials,
+                              float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay,
+                              int decoupled, float* norm_out, void* param_bf16, void* stream);
 
 /* --------------------------------------------------------------------------
  * One step of the masked-token parallel decode.
@@ -535,6 +543,13 @@ int amk_gemm_tn_bf16(const void* y, int64_t ldy, const void* x, int64_t ldx, flo
  * N, K and the leading dimensions multiples of 8 (N of 16 with epi 1); pointers 16-byte aligned; bias may be NULL. */
 int amk_gemm_bf16(int op, int epi, const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias,
                   void* c, int64_t ldc, void* g, int64_t ldg, int64_t M, int N, int K, void* stream);
+
+/* dab (M, 2 H) = (dA | dB): the backward of the SwiGLU gate applied to dG = dy (M, K) w3 (K, H), with the forward's
+ * ab (M, 2 H) = (a | b) -- the input gradient of the FFN's second projection and the gate's backward in one launch
+ * (models/vitvqgan.py:20-34, backward).  dG is rounded to bf16 before the gate's arithmetic (f32), exactly as
+ * amk_gemm_bf16(op 1) followed by amk_swiglu_bf16_bwd would; H, K and the leading dimensions multiples of 8. */
+int amk_gemm_bf16_swiglu_bwd(const void* dy, int64_t lddy, const void* w3, int64_t ldw, const void* ab, int64_t ldab,
+                             void* dab, int64_t lddab, int64_t M, int H, int K, void* stream);
 
 #ifdef __cplusplus
 }

@@ -168,3 +168,42 @@ def test_swiglu_ffn_under_autocast(device):
         assert u.dtype == torch.float32 and u.shape == v.shape
         assert rel_err(u, e) < 2e-2, name
         assert rel_err(u, e) < 1.5 * rel_err(v.float(), e) + 1e-3, f"{name}: no worse than the library path"
+
+
+@pytest.mark.parametrize("M,H,K", [(100, 64, 32), (300, 104, 40), (1000, 1368, 256), (129, 40, 256)])
+def test_nn_swiglu_backward_bf16(device, M, H, K):
+    """Bitwise the pair amk_gemm_bf16(op 1) + amk_swiglu_bf16_bwd (dG rounded to bf16 in between), and close to fp64."""
+    import ctypes
+
+    import torch.nn.functional as F
+
+    from amk import dense, lib
+
+    dy, w3, ab = seeded((M, K), 1).bfloat16().to(device), (seeded((K, H), 2) * K ** -0.5).bfloat16().to(device), seeded((M, 2 * H), 3).bfloat16().to(device)
+    out = dense.gemm_nn_swiglu_bwd_bf16(dy, w3, ab)
+    dg = dense.gemm_nn_bf16(dy, w3)
+    two = torch.empty_like(ab)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    lib.check(lib.load().amk_swiglu_bf16_bwd(P(ab), P(dg), M, H, P(two), ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "swiglu bwd")
+    assert rel_err(out.float(), two.float()) < 2 ** -7   # (rcp / exp2 against the other kernel's expf: last-bit differences)
+    abr = ab.double().cpu().requires_grad_(True)
+    g = F.silu(abr[:, :H]) * abr[:, H:]
+    (ref,) = torch.autograd.grad(g, abr, dy.double().cpu() @ w3.double().cpu())
+    assert rel_err(out.float(), ref) < 2e-2
+
+
+def test_swiglu_ffn_under_autocast_no_grad(device):
+    import torch.nn.functional as F
+
+    from amk import ops
+
+    D, H = 256, 1368
+    x = seeded((2, 300, D), 1).to(device)
+    w12, b12 = (seeded((2 * H, D), 2) * D ** -0.5).to(device), (seeded((2 * H,), 3) * 0.1).to(device)
+    w3, b3 = (seeded((D, H), 4) * H ** -0.5).to(device), (seeded((D,), 5) * 0.1).to(device)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        y = ops.swiglu_ffn(x, w12, b12, w3, b3)
+        a, b = F.linear(x, w12, b12).chunk(2, dim=-1)
+        y_ref = F.linear(F.silu(a) * b, w3, b3)
+    assert y.dtype == torch.bfloat16 and y.shape == y_ref.shape
+    assert rel_err(y.float(), y_ref.float()) < 2e-2

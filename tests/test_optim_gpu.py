@@ -68,3 +68,31 @@ def test_flat_adam_matches_torch(device, decoupled, wd, max_norm):
         assert st["step"] == int(rs["step"])
         assert_close(st["exp_avg"], rs["exp_avg"], 2e-6, n + " exp_avg")
         assert_close(st["exp_avg_sq"], rs["exp_avg_sq"], 2e-6, n + " exp_avg_sq")
+
+
+def test_flat_adam_bf16_shadow(device):
+    """bf16_shadow=True: after every step ``p._amk_bf16`` is exactly ``p.to(bfloat16)`` (parameters without a gradient
+    included: they keep their initial copy), and ops.linear under autocast reads it."""
+    from amk import ops
+    from amk.dp import GradReducer
+    from amk.optim import FlatAdam
+
+    torch.manual_seed(0)
+    net = Net().to(device)
+    red = GradReducer(net.parameters(), bucket_bytes=64 << 10)
+    opt = FlatAdam(red, lr=3e-3, bf16_shadow=True)
+    g = torch.Generator().manual_seed(1)
+    for step in range(3):
+        for p in net.parameters():
+            assert p._amk_bf16.dtype == torch.bfloat16 and p._amk_bf16.shape == p.shape
+            assert torch.equal(p._amk_bf16, p.detach().to(torch.bfloat16))
+        x = torch.randn(16, 37, generator=g).to(device)
+        red.begin(True)
+        net(x).pow(2).mean().backward()
+        red.finish(detach_unused=False)
+        opt.step(max_norm=1.0)
+    assert ops._w16(net.b.weight) is net.b.weight._amk_bf16
+    with torch.no_grad():
+        net.b.weight.mul_(2.0)
+    opt.refresh_shadow()
+    assert torch.equal(net.b.weight._amk_bf16, net.b.weight.detach().to(torch.bfloat16))
