@@ -59,14 +59,11 @@ class FlatAdam:
                 seg[off // ALIGN: off // ALIGN + nseg] = pid
                 pid += 1
             self.flat_p.append(fp)
-            if bf16_shadow:
-                f16 = fp.to(torch.bfloat16)
-                for p, off in zip(b.params, b.offsets):
-                    p._amk_bf16 = f16[off:off + p.numel()].view_as(p)
-                self.flat_p16.append(f16)
             self.m.append(torch.zeros_like(b.flat))
             self.v.append(torch.zeros_like(b.flat))
             self.seg.append(seg.to(dev))
+        if bf16_shadow:
+            self.enable_shadow()
         self.partials = torch.zeros(len(reducer.buckets) * self.npart, device=dev, dtype=torch.float32)
         self.norm = torch.zeros(1, device=dev, dtype=torch.float32)
         # per-step table {active, lr / bc1, sqrt(bc2), 0} per parameter: pinned host staging, async copy
@@ -79,6 +76,22 @@ class FlatAdam:
             self.steps_dev = torch.zeros(len(self.params), device=dev, dtype=torch.float64)
             self.lr_dev = torch.full((), float(lr), device=dev, dtype=torch.float64)
             self._fired_host, self._fired_dev = None, None
+
+    def enable_shadow(self):
+        """Start keeping bf16 copies of the parameters (see ``bf16_shadow``); idempotent."""
+        if self.flat_p16:
+            return self.refresh_shadow()
+        for b, fp in zip(self.red.buckets, self.flat_p):
+            f16 = fp.to(torch.bfloat16)
+            for p, off in zip(b.params, b.offsets):
+                p._amk_bf16 = f16[off:off + p.numel()].view_as(p)
+            self.flat_p16.append(f16)
+
+    def disable_shadow(self):
+        for p in self.params:
+            if hasattr(p, "_amk_bf16"):
+                del p._amk_bf16
+        self.flat_p16 = []
 
     def refresh_shadow(self):
         """Re-derive the bf16 copies from the fp32 parameters (after anything but ``step`` wrote them)."""

@@ -49,7 +49,7 @@ class VQGANTrainStep:
         # autocast: None (f32, the parity mode) or a dtype (torch.bfloat16): the forward passes and losses of both phases
         # run inside torch.autocast as the reference's do (trainers/vitgqgan.py:149,168 `accelerator.autocast()`);
         # parameters, gradients and optimizer state stay f32
-        self.autocast = autocast
+        self._autocast = autocast
         self.adv_w, self.laplace_w = adv_loss_weight, logit_laplace_weight
         self.max_grad_norm, self.gp_lambda = max_grad_norm, gp_lambda
         self.base_lr, self.warmup_steps, self.decay_steps = lr, warmup_steps, decay_steps
@@ -86,6 +86,20 @@ class VQGANTrainStep:
         # shipped config), one generator forward less.  Off by default: the step then mirrors the
         # reference call for call.
         self.share_forward = bool(share_forward)
+
+    @property
+    def autocast(self):
+        return self._autocast
+
+    @autocast.setter
+    def autocast(self, dtype):
+        """Switch precision modes between steps (not inside a captured graph: release_graph() first)."""
+        self._autocast = dtype
+        if self.fused_optimizer:
+            if dtype == torch.bfloat16:
+                self.g_optim.enable_shadow()
+            else:
+                self.g_optim.disable_shadow()
 
     def _amp(self):
         import contextlib

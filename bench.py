@@ -177,8 +177,33 @@ def bf16_attention_block(B, dev, iters):
     rel = lambda a, b: float((a.float() - b).abs().max() / b.abs().max())
     core = 4.0 * B * H * T * T * D
     t_b = t_fb - t_f
+    # the FFN's bf16 GEMMs (csrc/gemm_bf16.hip) at the layer shape: HBM-bound (tiny weights, every activation byte once)
+    from amk import dense
+
+    M, Dm, Hf = B * T, VIT["dim"], (int(VIT["mlp_dim"] * 2 / 3) + 7) // 8 * 8   # (the SwiGLU hidden width: 1368)
+    x = torch.randn(M, Dm, generator=g).to(dev).bfloat16()
+    w12 = (torch.randn(2 * Hf, Dm, generator=g) * Dm ** -0.5).to(dev).bfloat16()
+    b12 = torch.randn(2 * Hf, generator=g).to(dev)
+    w3 = (torch.randn(Dm, Hf, generator=g) * Hf ** -0.5).to(dev).bfloat16()
+    dy = torch.randn(M, Dm, generator=g).to(dev).bfloat16()
+    gg, ab = dense.gemm_nt_swiglu_bf16(x, w12, b12)
+    dab = dense.gemm_nn_swiglu_bwd_bf16(dy, w3, ab)
+    gemm_rows = []
+    for name, fn, nbytes, flop, per_step in [
+            ("gemm_bf16_kernel<NT, SwiGLU> (w12 + gate)", lambda: dense.gemm_nt_swiglu_bf16(x, w12, b12),
+             2.0 * (M * Dm + 2 * Hf * Dm + 3 * M * Hf), 4.0 * M * Dm * Hf, VIT["depth"]),
+            ("gemm_bf16_kernel<NN, SwiGLU bwd> (dY W3 + gate backward)", lambda: dense.gemm_nn_swiglu_bwd_bf16(dy, w3, ab),
+             2.0 * (M * Dm + Dm * Hf + 4 * M * Hf), 2.0 * M * Dm * Hf, VIT["depth"]),
+            ("gemm_tn_bf16 (dW12, db12)", lambda: dense.gemm_tn_bf16(dab, x, want_bias=True),
+             2.0 * (2 * M * Hf + M * Dm) + 4.0 * 2 * Hf * Dm, 4.0 * M * Dm * Hf, VIT["depth"]),
+            ("gemm_tn_bf16 (dW3, db3)", lambda: dense.gemm_tn_bf16(dy, gg, want_bias=True),
+             2.0 * (M * Hf + M * Dm) + 4.0 * Hf * Dm, 2.0 * M * Dm * Hf, VIT["depth"])]:
+        t = time_launches(fn, iters)
+        gemm_rows.append(dict(kernel=name, avg_launch_ms=t * 1e3, bound="hbm", achieved=nbytes / t / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                              frac=nbytes / t / 1e9 / HBM_PEAK_GBS, bytes_per_launch=nbytes, tflops=flop / t / 1e12, launches_per_step=per_step))
+    del x, w12, b12, w3, dy, gg, ab, dab
     return {"roofline_bf16": {
-        "bound": "mfma", "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "bound": "mfma", "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "gemm_kernels": gemm_rows,
         "kernels": [dict(kernel="attn_bf16_fwd_kernel", avg_launch_ms=t_f * 1e3, achieved=core / t_f / 1e12,
                          frac=core / t_f / 1e12 / BF16_MFMA_PEAK_TFLOPS, flop_per_launch=core, launches_per_step=4 * VIT["depth"]),
                     dict(kernel="attn_bf16_bwd (delta + fused + dq reduce)", avg_launch_ms=t_b * 1e3,
@@ -425,7 +450,9 @@ def main():
         # its own dtype, its own roofline -- never the headline (the north star's tolerance is an f32 one)
         v16 = variant(lambda: setattr(trainer, "autocast", torch.bfloat16), lambda: setattr(trainer, "autocast", None),
                       "both phases' forwards and losses under torch.autocast(bfloat16) as the reference's accelerator.autocast() "
-                      "blocks run them (trainers/vitgqgan.py:149,170): Linear / convolution GEMMs in bf16 (vendor library), "
+                      "blocks run them (trainers/vitgqgan.py:149,170): Linear GEMMs in bf16 (weight / bias gradients, the w12 + SwiGLU forward and the dY W3 + "
+                      "SwiGLU backward on csrc/gemm_bf16.hip, the rest on the vendor library; bf16 parameter copies refreshed by the optimizer "
+                      "kernel), discriminator convolutions in bf16 (MIOpen), "
                       "attention on the bf16-MFMA kernels of csrc/attn_bf16.hip (bf16 operands, f32 scores / softmax / "
                       "accumulators), VQ lookup exact f32; parameters, gradients and optimizer state f32; not the headline value")
         v16["dtype"] = "bf16 (autocast)"
