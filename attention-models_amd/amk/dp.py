@@ -22,6 +22,12 @@ Design (MI355X: 7 xGMI links x ~153 GB/s per GPU, ring collectives are per-link 
     wrap would raise), makes the compute stream wait for the side stream, and detaches ``.grad``
     of the parameters that received none since the last ``zero_grad()`` -- torch optimizers then
     skip them as they do in the reference (no weight decay, no moment update);
+  * the set of parameters that receive no gradient is taken to be static (``static_unused=True``, DDP's
+    ``static_graph``): the first synchronised step records it -- as the UNION over ranks of the parameters that fired,
+    one small blocking MAX all-reduce, so that "unused" is decided globally and every rank skips or updates the same
+    parameters -- and later steps do not wait for those parameters before sending their buckets (without this, one
+    W_d in the first bucket keeps every all-reduce until ``finish()``: no overlap for SwitchHead / Agent models).  A
+    recorded-unused parameter that does fire after its bucket left raises; ``reset_static()`` re-records;
   * ``begin(sync=False)`` skips communication for gradient-accumulation micro-steps
     (``accelerator.accumulate`` / ``no_sync`` semantics).
 Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 tests).
@@ -33,16 +39,17 @@ ALIGN = 256  # elements: a parameter's slice of its bucket starts on a 1-KiB bou
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "offsets", "pending", "ready", "launched", "work", "fired")
+    __slots__ = ("flat", "params", "views", "offsets", "pending", "ready", "launched", "work", "fired", "static_unused")
 
     def __init__(self, flat, params, views, offsets):
         self.flat, self.params, self.views, self.offsets = flat, params, views, offsets
         self.pending, self.ready, self.launched, self.work = len(params), False, False, None
         self.fired = [False] * len(params)
+        self.static_unused = None  # per parameter: never receives a gradient on any rank (recorded by the first sync step)
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, communicate_when_alone=False):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, communicate_when_alone=False, static_unused=True):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradReducer: no trainable parameters")
@@ -56,6 +63,7 @@ class GradReducer:
         self.avg_in_collective = (not self.alone) and dist.get_backend(process_group) == "nccl"
         self.side = torch.cuda.Stream(device=dev) if self.on_gpu else None
         self.sync_step = True
+        self.static_unused = bool(static_unused)
         self.buckets = []
         self._bucket_of = {}
         self._next = 0  # index of the next bucket to send
@@ -105,6 +113,9 @@ class GradReducer:
         self.launch_order = []
         for b in self.buckets:
             b.pending, b.ready, b.launched, b.work = len(b.params), False, False, None
+            if b.static_unused is not None:
+                b.pending -= sum(b.static_unused)  # not waited for
+                b.ready = b.pending == 0           # only such parameters: its zeros leave with the first bucket that completes
             for p, v in zip(b.params, b.views):
                 if p.grad is None:
                     p.grad = v  # detached by finish() of an earlier step: accumulate into the bucket again
@@ -130,6 +141,12 @@ class GradReducer:
             view.copy_(p.grad)  # autograd (create_graph) or an optimizer replaced .grad: fold it back
             p.grad = view
         b.fired[i] = True
+        if b.static_unused is not None and b.static_unused[i]:
+            if b.launched and not self.alone:
+                raise RuntimeError("GradReducer: a parameter recorded as never receiving a gradient received one after its "
+                                   "bucket was sent; call reset_static() when the set of used parameters changes "
+                                   "(or construct with static_unused=False)")
+            return  # not counted in pending
         b.pending -= 1
         if b.pending == 0:
             b.ready = True
@@ -176,11 +193,39 @@ class GradReducer:
                         b.work.wait()
                         b.flat.mul_(1.0 / self.world)
                         b.work = None
+        self._settle_unused()
         if detach_unused:
             for b in self.buckets:
                 for p, f in zip(b.params, b.fired):
                     if not f:
                         p.grad = None  # the reference leaves .grad None here: optimizers skip the parameter
+
+    def reset_static(self):
+        """Forget which parameters never receive gradients; the next synchronised step records the set again."""
+        for b in self.buckets:
+            b.static_unused = None
+
+    def _settle_unused(self):
+        """Decide "unused" globally: a parameter is skipped only if it fired on NO rank (otherwise a rank where it did not
+        fire would skip an update the others apply, and the replicas drift apart).  Static mode: one blocking MAX
+        all-reduce of the fired flags at the first synchronised step, reused afterwards; else one per step."""
+        recorded = all(b.static_unused is not None for b in self.buckets)
+        if self.static_unused and recorded:
+            for b in self.buckets:
+                b.fired = [f or not u for f, u in zip(b.fired, b.static_unused)]
+            return
+        flags = [f for b in self.buckets for f in b.fired]
+        if not self.alone:
+            dev = self.buckets[0].flat.device
+            t = torch.tensor(flags, dtype=torch.float32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            flags = [bool(x) for x in t.cpu().tolist()]
+        k = 0
+        for b in self.buckets:
+            b.fired = flags[k:k + len(b.params)]
+            k += len(b.params)
+            if self.static_unused:
+                b.static_unused = [not f for f in b.fired]
 
     def unused_parameters(self):
         """Parameters that received no gradient since the last zero_grad()."""

@@ -6,6 +6,7 @@ is deliberately no CPU / eager path ("no fallback").
 """
 import ctypes
 import os
+import weakref
 
 import torch
 
@@ -116,9 +117,23 @@ ATTENTION_FORWARD = os.environ.get("AMK_ATTENTION_FORWARD", "f32")
 # backward reads them back instead of recomputing S = QK^T -- four matrix products instead of five, bit for
 # bit the same results.  The reference keeps the same tensor alive for autograd; 288 GB of HBM make it
 # affordable here (1.07 GB per ViT-VQGAN layer at batch 32, 12.9 GB for the twelve layers).  A call whose
-# scores would exceed ATTENTION_KEEP_SCORES_MAX_BYTES recomputes instead.
+# scores would exceed ATTENTION_KEEP_SCORES_MAX_BYTES, or that would take the scores alive across all layers beyond
+# ATTENTION_KEEP_SCORES_BUDGET_BYTES (default: a quarter of the device's memory), recomputes instead -- the same
+# results from five products, so a deeper model or a larger batch degrades in speed, not into an out-of-memory error.
 ATTENTION_KEEP_SCORES = os.environ.get("AMK_ATTN_KEEP_SCORES", "1") == "1"
 ATTENTION_KEEP_SCORES_MAX_BYTES = 8 << 30
+ATTENTION_KEEP_SCORES_BUDGET_BYTES = int(os.environ.get("AMK_ATTN_KEEP_BUDGET", "0")) or None   # None: memory / 4
+_kept_scores_bytes = [0]   # bytes of kept scores alive right now (released when the tensors are freed)
+
+
+def _keep_budget(device):
+    if ATTENTION_KEEP_SCORES_BUDGET_BYTES is not None:
+        return ATTENTION_KEEP_SCORES_BUDGET_BYTES
+    return torch.cuda.get_device_properties(device).total_memory // 4
+
+
+def _release_kept(nbytes):
+    _kept_scores_bytes[0] -= nbytes
 # keys per workgroup of the fused backward: 0 = library default, 128 or 256
 ATTENTION_BACKWARD_KEYS = int(os.environ.get("AMK_ATTN_BWD_KEYS", "0"))
 
@@ -140,8 +155,10 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=False):
     if (keep_scores and D == 64 and not x6 and causal_mask is None and ATTENTION_KEEP_SCORES
             and not ATTENTION_BACKWARD_TWO_KERNEL):
         nbytes = L.amk_attn_scores_bytes(B, H, I, J)
-        if nbytes <= ATTENTION_KEEP_SCORES_MAX_BYTES:
+        if nbytes <= ATTENTION_KEEP_SCORES_MAX_BYTES and _kept_scores_bytes[0] + nbytes <= _keep_budget(q.device):
             scores = torch.empty((nbytes // 4,), device=q.device, dtype=torch.float32)
+            _kept_scores_bytes[0] += nbytes
+            weakref.finalize(scores.untyped_storage(), _release_kept, nbytes)
     with _timed("attn_fwd_keep_kernel" if scores is not None else "attn_fwd_kernel"):
         if scores is not None:
             rc = L.amk_attn_fwd_keep(
@@ -1023,8 +1040,14 @@ def gemm_x6_nt(a2, b2, bias=None):
 
 
 def _x6_ok(x, weight):
+    """The preconditions of amk_gemm_x6_nt (csrc/gemm_x6.hip), so that other shapes take the library GEMM instead of
+    an error from the C side: rows 16-byte aligned (K and the leading dimensions multiples of 4), operands < 2 GiB."""
     K = weight.shape[1]
-    return K % 4 == 0 and x.numel() > 0 and x.data_ptr() % 16 == 0 and weight.data_ptr() % 16 == 0
+    if K % 4 or x.numel() == 0 or x.data_ptr() % 16 or weight.data_ptr() % 16:
+        return False
+    if x.stride(-1) != 1 or (x.dim() >= 2 and x.stride(-2) % 4):
+        return False
+    return x.numel() * 4 < 0x7ffffff0 and weight.numel() * 8 < 0x7ffffff0   # (A's span; the three bf16 planes of W, padded)
 
 
 class _LinearX6(torch.autograd.Function):

@@ -345,3 +345,4 @@ def test_torch_deterministic_mode_selects_reproducible_backward(device, backward
     finally:
         torch.use_deterministic_algorithms(False)
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
+

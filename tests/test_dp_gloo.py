@@ -192,3 +192,69 @@ def test_two_rank_train_step_matches_accumulated_single_process(tmp_path):
             assert torch.equal(r0[part][n], r1[part][n]), (part, n)  # ranks stay in lockstep
             assert torch.allclose(r0[part][n], one[part][n], rtol=2e-4, atol=2e-6), (part, n)  # summation order only
     assert torch.equal(r0["gen"]["never_used"], torch.ones(5))
+
+
+# ---------------------------------------------------------------------------------------------
+class GatedNet(nn.Module):
+    """`head` (registered LAST, so it sits in bucket 0) never gets a gradient; `skip` is bypassed on rank 1 only."""
+
+    def __init__(self):
+        super().__init__()
+        self.a = nn.Linear(8, 16)
+        self.skip = nn.Linear(16, 16)
+        self.b = nn.Linear(16, 4)
+        self.head = nn.Linear(3, 3)
+
+    def forward(self, x, use_skip):
+        h = torch.tanh(self.a(x))
+        if use_skip:
+            h = h + self.skip(h)
+        return self.b(h)
+
+
+def _worker_static(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "attention-models_amd"))
+    from amk.dp import GradReducer
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(5)
+    net = GatedNet()
+    red = GradReducer(net.parameters(), bucket_bytes=256)
+    assert any(p is net.head.bias for p in red.buckets[0].params)   # a never-used parameter is in the first bucket
+    opt = torch.optim.SGD(net.parameters(), lr=0.1)
+    x, y = _data(world)
+    xs, ys = x.chunk(world)[rank], y.chunk(world)[rank]
+    early = []
+    for step in range(3):
+        red.begin(sync=True)
+        ((net(xs, use_skip=rank == 0) - ys) ** 2).mean().backward()
+        early.append(list(red.launch_order))        # buckets that left BEFORE finish()
+        red.finish()
+        # `skip` fired on rank 0 only: it must count as used on BOTH ranks (rank 1 applies the averaged gradient)
+        assert net.skip.weight.grad is not None and net.head.weight.grad is None
+        opt.step()
+        red.zero_grad()
+    # step 0 records the static set (nothing can leave before bucket 0 is complete, and `head` never completes it);
+    # from step 1 on the buckets whose used parameters all fired leave during backward
+    assert early[0] == [] and len(early[1]) > 0 and early[1][0] == 0, early
+    torch.save({n: p.detach().clone() for n, p in net.named_parameters()}, os.path.join(out_dir, f"static{rank}.pt"))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_static_unused_parameters_do_not_block_and_are_decided_globally(tmp_path):
+    world = 2
+    mp.spawn(_worker_static, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(tmp_path / "static0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "static1.pt", weights_only=True)
+    for n in r0:
+        assert torch.equal(r0[n], r1[n]), f"{n}: the replicas drifted apart"
+    torch.manual_seed(5)
+    fresh = GatedNet()
+    assert not torch.equal(r0["skip.weight"], fresh.skip.weight)   # updated (on both ranks) ...
+    assert torch.equal(r0["head.weight"], fresh.head.weight)       # ... and the never-used one untouched
