@@ -69,6 +69,12 @@ __device__ __forceinline__ void fma4(float4& a, float s, const float4& x) {
 __device__ __forceinline__ void mad4(float4& a, const float4& w, const float4& x) {
   a.x += w.x * x.x; a.y += w.y * x.y; a.z += w.z * x.z; a.w += w.w * x.w;
 }
+// barrier that orders LDS only: global loads issued before it stay in flight across it (__syncthreads() drains them)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 __host__ __device__ __forceinline__ int bin_lo(int i, int T, int P) { return (int)(((int64_t)i * T) / P); }
 __host__ __device__ __forceinline__ int bin_hi(int i, int T, int P) { return (int)((((int64_t)(i + 1)) * T + P - 1) / P); }
 
@@ -81,6 +87,22 @@ __device__ __forceinline__ void stage_rows(float* tile, const float* base, int64
     const int r = r0 + (tid >> 4), t = t0 + r;
     st4(tile + r * TS + c4, t < T ? ld4(base + (int64_t)t * st + c4) : f4(0.f));
   }
+}
+// the same in two halves: request the pieces (registers), put them into the tile later -- the second tile of a kernel
+// is in flight while the first one is worked on
+constexpr int NPIECE = CH / (NT / 16);
+__device__ __forceinline__ void fetch_rows(float4 (&pc)[NPIECE], const float* base, int64_t st, int t0, int T, int tid) {
+  const int c4 = (tid & 15) * 4;
+#pragma unroll
+  for (int j = 0; j < NPIECE; ++j) {
+    const int t = t0 + (NT / 16) * j + (tid >> 4);
+    pc[j] = t < T ? ld4(base + (int64_t)t * st + c4) : f4(0.f);
+  }
+}
+__device__ __forceinline__ void put_rows(float* tile, const float4 (&pc)[NPIECE], int tid) {
+  const int c4 = (tid & 15) * 4;
+#pragma unroll
+  for (int j = 0; j < NPIECE; ++j) st4(tile + ((NT / 16) * j + (tid >> 4)) * TS + c4, pc[j]);
 }
 // tile[CH][TS] -> rows [t0, min(t0+CH, T)) of a (T, D) view
 __device__ __forceinline__ void unstage_rows(const float* tile, float* base, int64_t st, int t0, int T, int tid) {
@@ -122,6 +144,13 @@ __device__ __forceinline__ float fold4(const float* red, int i, int lane) {
   return red[(0 * MAXP + i) * D + lane] + red[(1 * MAXP + i) * D + lane] + red[(2 * MAXP + i) * D + lane] +
          red[(3 * MAXP + i) * D + lane];
 }
+
+#ifdef AMK_AGENT_STAMPS   // diagnostic build (tools/scratch/stamps_agent.py): per-workgroup time stamps of s2_bwd
+__device__ unsigned long long* g_stamps = nullptr;
+#define AG_STAMP(i) do { if (threadIdx.x == 0 && g_stamps) g_stamps[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define AG_STAMP(i) do { } while (0)
+#endif
 
 // blockIdx -> (b, h, chunk); chunk fastest so neighbouring workgroups share the conv halo rows in L2
 struct Where { int b, h, ch, t0; int64_t bh; };
@@ -175,7 +204,16 @@ __global__ __launch_bounds__(NT) void agent_s1_partial_kernel(Params p) {
 
   for (int i = wave; i < P; i += 4) As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane] * p.scale;
   stage_rows(tile, kb, p.ks.st, t0, T, tid);
-  __syncthreads();
+  // the value rows of phase B (16 lanes per row, 16 rows per pass) are requested NOW and arrive under phase A: the
+  // barriers in between order LDS only
+  const int sub = tid >> 4, c4 = (tid & 15) * 4;
+  float4 vrow[CH / (NT / 16)];
+#pragma unroll
+  for (int j = 0; j < CH / (NT / 16); ++j) {
+    const int t = t0 + (NT / 16) * j + sub;
+    vrow[j] = t < T ? ld4(vb + (int64_t)t * p.vs.st + c4) : f4(0.f);
+  }
+  lds_barrier();
   {  // phase A: two threads per key
     const int tok = tid >> 1, half = tid & 1;
     float kr[HALF];
@@ -188,30 +226,26 @@ __global__ __launch_bounds__(NT) void agent_s1_partial_kernel(Params p) {
       }
     }
   }
-  __syncthreads();
+  lds_barrier();
   for (int i = wave; i < P; i += 4) {  // chunk max per agent: one wave per agent
     float m = fmaxf(S[i * CH + lane], S[i * CH + 64 + lane]);
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if (lane == 0) mloc[i] = m;  // finite: every chunk holds at least one key
   }
-  __syncthreads();
-  for (int e = tid; e < P * CH; e += NT) S[e] = expf(S[e] - mloc[e / CH]);
-  __syncthreads();
+  lds_barrier();
+  for (int e = tid; e < P * CH; e += NT) S[e] = expf(S[e] - mloc[e / CH]);   // (rows past T: exp(-inf) = 0)
+  lds_barrier();
   {  // phase B: 16 lanes per value row, 16 rows of the chunk per pass
-    const int sub = tid >> 4, c4 = (tid & 15) * 4;
     float4 acc[PM];
 #pragma unroll
     for (int i = 0; i < PM; ++i) acc[i] = f4(0.f);
-#pragma unroll 2
-    for (int r0 = 0; r0 < CH; r0 += NT / 16) {
-      const int r = r0 + sub;
-      if (t0 + r < T) {
-        const float4 vv = ld4(vb + (int64_t)(t0 + r) * p.vs.st + c4);
 #pragma unroll
-        for (int i = 0; i < PM; ++i)
-          if (i < P) fma4(acc[i], S[i * CH + r], vv);
-      }
+    for (int j = 0; j < CH / (NT / 16); ++j) {
+      const int r = (NT / 16) * j + sub;
+#pragma unroll
+      for (int i = 0; i < PM; ++i)
+        if (i < P) fma4(acc[i], S[i * CH + r], vrow[j]);
     }
 #pragma unroll
     for (int i = 0; i < PM; ++i) {
@@ -308,7 +342,23 @@ __global__ __launch_bounds__(NT) void agent_s2_kernel(Params p) {
 
   for (int i = wave; i < P; i += 4) As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane] * p.scale;
   stage_rows(tile, qb, p.qs.st, t0, T, tid);
-  __syncthreads();
+  // phase B mapping: 16 lanes per output row, and a 16-lane group takes CH / 16 CONSECUTIVE rows, so that the 3x3
+  // window of the depthwise convolution slides: three new value rows (heads h-1, h, h+1) per output row instead of
+  // nine.  The first rows of the window are requested now and arrive under phase A (LDS-only barriers in between).
+  constexpr int RPG = CH / (NT / 16);   // rows per group
+  const int grp = tid >> 4, c4 = (tid & 15) * 4;
+  const float* vbatch = p.v + (int64_t)w.b * p.vs.sb;
+  auto ldv = [&](int a, int t) {   // value row of head h + a - 1 at token t, channels c4..c4+3; zero padding
+    const int h2 = w.h + a - 1;
+    return (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? ld4(vbatch + (int64_t)h2 * p.vs.sh + (int64_t)t * p.vs.st + c4) : f4(0.f);
+  };
+  const int tfirst = t0 + RPG * grp;
+  float4 win[3][4];   // [head offset][token slot]: tokens t-1, t, t+1 and the prefetched t+2
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    win[a][0] = ldv(a, tfirst - 1); win[a][1] = ldv(a, tfirst); win[a][2] = ldv(a, tfirst + 1); win[a][3] = ldv(a, tfirst + 2);
+  }
+  lds_barrier();
   {  // phase A: two threads per token: p scores, softmax over the agents
     const int tok = tid >> 1, half = tid & 1;
     float qr[HALF];
@@ -328,26 +378,30 @@ __global__ __launch_bounds__(NT) void agent_s2_kernel(Params p) {
         if (i < P) S[i * CH + tok] = sc[i] / l;
     }
   }
-  __syncthreads();
-  {  // phase B: 16 lanes per output row
-    const int sub = tid >> 4, c4 = (tid & 15) * 4;
+  lds_barrier();
+  {  // phase B
     float4 wq[9], var[PM];
     load_taps(p.convw, c4, wq);
     const float4 cb = ld4(p.convb + c4);
 #pragma unroll
     for (int i = 0; i < PM; ++i) var[i] = (i < P) ? ld4(p.vagent + (w.bh * P + i) * D + c4) : f4(0.f);
-    const float* vbatch = p.v + (int64_t)w.b * p.vs.sb;
     float* ob = p.o + (int64_t)w.b * p.os.sb + (int64_t)w.h * p.os.sh;
-#pragma unroll 2
-    for (int r0 = 0; r0 < CH; r0 += NT / 16) {
-      const int r = r0 + sub, t = t0 + r;
-      if (t < T) {
-        float4 o = cb;
-        conv4<false>(o, vbatch, p.vs, p.H, T, w.h, t, c4, wq);
 #pragma unroll
-        for (int i = 0; i < PM; ++i)
-          if (i < P) fma4(o, S[i * CH + r], var[i]);
-        st4(ob + (int64_t)t * p.os.st + c4, o);
+    for (int j = 0; j < RPG; ++j) {
+      const int r = RPG * grp + j, t = t0 + r;
+      float4 o = cb;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) mad4(o, wq[a * 3 + b], win[a][b]);
+#pragma unroll
+      for (int i = 0; i < PM; ++i)
+        if (i < P) fma4(o, S[i * CH + r], var[i]);
+      if (t < T) st4(ob + (int64_t)t * p.os.st + c4, o);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        win[a][0] = win[a][1]; win[a][1] = win[a][2]; win[a][2] = win[a][3];
+        win[a][3] = (j + 3 <= RPG) ? ldv(a, t + 3) : f4(0.f);   // (row t+3 is the last one the group's window needs)
       }
     }
   }
@@ -373,12 +427,34 @@ __global__ __launch_bounds__(NT) void agent_s2_bwd_kernel(BwdParams p) {
   float* dqb = p.dq + (int64_t)w.b * p.dqs.sb + (int64_t)h * p.dqs.sh;
   const float* vbatch = p.v + (int64_t)w.b * p.vs.sb;
 
+  AG_STAMP(0);
   for (int i = wave; i < P; i += 4) {
     As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane];
     Vas[i * D + lane] = p.vagent[(w.bh * P + i) * D + lane];
   }
   stage_rows(tile, qb, p.qs.st, t0, T, tid);
-  __syncthreads();
+  float4 gpc[NPIECE];
+  fetch_rows(gpc, gb, p.dos.st, t0, T, tid);   // the dO tile: in flight while the q tile is worked on
+  // phase B (below): 16 lanes per row, a 16-lane group takes CH / 16 CONSECUTIVE rows: the 3x3 window of value rows behind
+  // the convolution's weight gradient slides (three new rows per token instead of nine), rows two tokens ahead in
+  // flight; its first rows are requested here, a whole phase early
+  constexpr int RPG = CH / (NT / 16);
+  const int grp = tid >> 4, c4 = (tid & 15) * 4;
+  auto ldv = [&](int a, int t) {
+    const int h2 = h + a - 1;
+    return (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? ld4(vbatch + (int64_t)h2 * p.vs.sh + (int64_t)t * p.vs.st + c4) : f4(0.f);
+  };
+  auto ldrow = [&](const float* base, int64_t st, int t) { return t < T ? ld4(base + (int64_t)t * st + c4) : f4(0.f); };
+  const int tfirst = t0 + RPG * grp;
+  float4 win[3][4], gq[2][3];   // value window [head offset][t-1, t, t+1, t+2]; dO / q rows [t, t+1, t+2]
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    win[a][0] = ldv(a, tfirst - 1); win[a][1] = ldv(a, tfirst); win[a][2] = ldv(a, tfirst + 1); win[a][3] = ldv(a, tfirst + 2);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { gq[0][k] = ldrow(gb, p.dos.st, tfirst + k); gq[1][k] = ldrow(qb, p.qs.st, tfirst + k); }
+  lds_barrier();
+  AG_STAMP(1);
   {  // phase A: two threads per token
     const int tok = tid >> 1, half = tid & 1;
     const bool ok = t0 + tok < T;
@@ -390,9 +466,10 @@ __global__ __launch_bounds__(NT) void agent_s2_bwd_kernel(BwdParams p) {
       for (int i = 0; i < PM; ++i)
         if (i < P) sc[i] = dot_half(qr, &As[i * D], half) * p.scale;
     }
-    __syncthreads();
-    stage_rows(tile, gb, p.dos.st, t0, T, tid);
-    __syncthreads();
+    lds_barrier();
+    put_rows(tile, gpc, tid);
+    lds_barrier();
+    AG_STAMP(2);
     {
       float gr[HALF];
       load_half(tile, tok, half, gr);
@@ -435,42 +512,44 @@ __global__ __launch_bounds__(NT) void agent_s2_bwd_kernel(BwdParams p) {
     }
   }
   __syncthreads();
+  AG_STAMP(3);
   unstage_rows(tile, dqb, p.dqs.st, t0, T, tid);
-  const int sub = tid >> 4, c4 = (tid & 15) * 4;
   float4 accva[PM], acca[PM], dw9[9], dbs = f4(0.f);
 #pragma unroll
   for (int i = 0; i < PM; ++i) { accva[i] = f4(0.f); acca[i] = f4(0.f); }
 #pragma unroll
   for (int j = 0; j < 9; ++j) dw9[j] = f4(0.f);
-  {  // phase B: 16 lanes per row
-    for (int r0 = 0; r0 < CH; r0 += NT / 16) {
-      const int r = r0 + sub, t = t0 + r;
-      if (t < T) {
-        const float4 g = ld4(gb + (int64_t)t * p.dos.st + c4);
-        const float4 qv = ld4(qb + (int64_t)t * p.qs.st + c4);
+  {
+#pragma unroll 1
+    for (int j = 0; j < RPG; ++j) {
+      const int r = RPG * grp + j, t = t0 + r;
+      const float4 g = gq[0][0], qv = gq[1][0];   // (rows past T: zeros, and S / DS are zero there)
 #pragma unroll
-        for (int i = 0; i < PM; ++i) {
-          if (i < P) {
-            fma4(accva[i], S[i * CH + r], g);
-            fma4(acca[i], DS[i * CH + r], qv);
-          }
+      for (int i = 0; i < PM; ++i) {
+        if (i < P) {
+          fma4(accva[i], S[i * CH + r], g);
+          fma4(acca[i], DS[i * CH + r], qv);
         }
-        dbs.x += g.x; dbs.y += g.y; dbs.z += g.z; dbs.w += g.w;
+      }
+      dbs.x += g.x; dbs.y += g.y; dbs.z += g.z; dbs.w += g.w;
 #pragma unroll
-        for (int a = 0; a < 3; ++a) {
-          const int h2 = h + a - 1;
-          if (h2 < 0 || h2 >= p.H) continue;
+      for (int a = 0; a < 3; ++a)
 #pragma unroll
-          for (int bb = 0; bb < 3; ++bb) {
-            const int t2 = t + bb - 1;
-            if (t2 < 0 || t2 >= T) continue;
-            mad4(dw9[a * 3 + bb], g, ld4(vbatch + (int64_t)h2 * p.vs.sh + (int64_t)t2 * p.vs.st + c4));
-          }
-        }
+        for (int bb = 0; bb < 3; ++bb) mad4(dw9[a * 3 + bb], g, win[a][bb]);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        win[a][0] = win[a][1]; win[a][1] = win[a][2]; win[a][2] = win[a][3];
+        win[a][3] = (j + 3 <= RPG) ? ldv(a, t + 3) : f4(0.f);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        gq[k][0] = gq[k][1]; gq[k][1] = gq[k][2];
+        gq[k][2] = (j + 3 < RPG) ? ldrow(k == 0 ? gb : qb, k == 0 ? p.dos.st : p.qs.st, t + 3) : f4(0.f);
       }
     }
   }
   const int64_t cell = w.bh * p.NC + w.ch;
+  AG_STAMP(4);
   __syncthreads();  // the dq rows have left the tile
 #pragma unroll
   for (int i = 0; i < PM; ++i) {
@@ -506,6 +585,7 @@ __global__ __launch_bounds__(NT) void agent_s2_bwd_kernel(BwdParams p) {
     for (int j = 0; j < 9; ++j) p.dconvw_part[(cell * 9 + j) * D + lane] = fold4(red, j, lane);
     p.dconvb_part[cell * D + lane] = fold4(red, 9, lane);
   }
+  AG_STAMP(5);
 }
 
 // backward 1: fold the stage-2 partials in chunk order: dV_agent, dA (stage 2), delta1 = <dV_agent, V_agent>.
@@ -559,7 +639,9 @@ __global__ __launch_bounds__(NT) void agent_s1_bwd_kernel(BwdParams p) {
     if (lane == 0) { m1[i] = p.stats1[row * 2]; l1[i] = p.stats1[row * 2 + 1]; delta1[i] = p.delta1[row]; }
   }
   stage_rows(tile, kb, p.ks.st, t0, T, tid);
-  __syncthreads();
+  float4 vpc[NPIECE];
+  fetch_rows(vpc, vb, p.vs.st, t0, T, tid);   // the v tile: in flight while the k tile is worked on
+  lds_barrier();
   {  // phase A: two threads per key
     const int tok = tid >> 1, half = tid & 1;
     const bool ok = t0 + tok < T;
@@ -571,9 +653,9 @@ __global__ __launch_bounds__(NT) void agent_s1_bwd_kernel(BwdParams p) {
       for (int i = 0; i < PM; ++i)
         if (i < P) pr[i] = expf(dot_half(kr, &As[i * D], half) * p.scale - m1[i]) / l1[i];
     }
-    __syncthreads();
-    stage_rows(tile, vb, p.vs.st, t0, T, tid);
-    __syncthreads();
+    lds_barrier();
+    put_rows(tile, vpc, tid);
+    lds_barrier();
     {
       float vr[HALF];
       load_half(tile, tok, half, vr);
@@ -603,30 +685,53 @@ __global__ __launch_bounds__(NT) void agent_s1_bwd_kernel(BwdParams p) {
   }
   __syncthreads();
   unstage_rows(tile, dkb, p.dks.st, t0, T, tid);
-  const int sub = tid >> 4, c4 = (tid & 15) * 4;
+  // phase B: 16 lanes per row, CH / 16 consecutive rows per 16-lane group: the 3x3 window of dO rows behind the transposed
+  // depthwise convolution slides (three new rows per token instead of nine)
+  constexpr int RPG = CH / (NT / 16);
+  const int grp = tid >> 4, c4 = (tid & 15) * 4;
   float4 acca[PM];
-  {  // phase B: 16 lanes per row
+  {
     float4 wq[9], dva[PM];
     load_taps(p.convw, c4, wq);
 #pragma unroll
     for (int i = 0; i < PM; ++i) { acca[i] = f4(0.f); dva[i] = (i < P) ? ld4(&dVas[i * D + c4]) : f4(0.f); }
-#pragma unroll 2
-    for (int r0 = 0; r0 < CH; r0 += NT / 16) {
-      const int r = r0 + sub, t = t0 + r;
-      if (t < T) {
-        const float4 kv = ld4(kb + (int64_t)t * p.ks.st + c4);
-        float4 dvv = f4(0.f);
-        // transposed depthwise conv: dv[h,t] += sum w[a][b] * dO[h-(a-1), t-(b-1)]
-        conv4<true>(dvv, gbatch, p.dos, p.H, T, h, t, c4, wq);
+    // dv[h, t] += sum_{a, b} w[a][b] dO[h - (a - 1), t - (b - 1)]: window slot s holds dO[., t - 1 + s] of head h + 1 - a
+    auto ldg = [&](int a, int t) {
+      const int h2 = h - (a - 1);
+      return (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? ld4(gbatch + (int64_t)h2 * p.dos.sh + (int64_t)t * p.dos.st + c4) : f4(0.f);
+    };
+    const int tfirst = t0 + RPG * grp;
+    float4 win[3][4], krow[3];
 #pragma unroll
-        for (int i = 0; i < PM; ++i) {
-          if (i < P) {
-            fma4(acca[i], DS[i * CH + r], kv);
-            fma4(dvv, S[i * CH + r], dva[i]);
-          }
+    for (int a = 0; a < 3; ++a) {
+      win[a][0] = ldg(a, tfirst - 1); win[a][1] = ldg(a, tfirst); win[a][2] = ldg(a, tfirst + 1); win[a][3] = ldg(a, tfirst + 2);
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) krow[k] = tfirst + k < T ? ld4(kb + (int64_t)(tfirst + k) * p.ks.st + c4) : f4(0.f);
+#pragma unroll 1
+    for (int j = 0; j < RPG; ++j) {
+      const int r = RPG * grp + j, t = t0 + r;
+      const float4 kv = krow[0];
+      float4 dvv = f4(0.f);
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bb = 0; bb < 3; ++bb) mad4(dvv, wq[a * 3 + bb], win[a][2 - bb]);   // token t - (bb - 1) = slot 2 - bb
+#pragma unroll
+      for (int i = 0; i < PM; ++i) {
+        if (i < P) {
+          fma4(acca[i], DS[i * CH + r], kv);
+          fma4(dvv, S[i * CH + r], dva[i]);
         }
-        st4(dvb + (int64_t)t * p.dvs.st + c4, dvv);
       }
+      if (t < T) st4(dvb + (int64_t)t * p.dvs.st + c4, dvv);
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        win[a][0] = win[a][1]; win[a][1] = win[a][2]; win[a][2] = win[a][3];
+        win[a][3] = (j + 3 <= RPG) ? ldg(a, t + 3) : f4(0.f);
+      }
+      krow[0] = krow[1]; krow[1] = krow[2];
+      krow[2] = (j + 3 < RPG && t + 3 < T) ? ld4(kb + (int64_t)(t + 3) * p.ks.st + c4) : f4(0.f);
     }
   }
   __syncthreads();  // the dk rows have left the tile
@@ -769,3 +874,21 @@ extern "C" int amk_agent_attn_bwd(const float* q, const float* k, const float* v
   AMK_CHECK_LAUNCH("amk_agent_attn_bwd");
   return AMK_OK;
 }
+
+// diagnostic (not part of the ABI): resident workgroups per CU the runtime computes for the chunk kernels
+extern "C" int amk_debug_agent_occupancy(int which) {
+  int n = -1;
+  hipError_t e;
+  if (which == 0) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, amk_agent::agent_s1_partial_kernel<8>, amk_agent::NT, 0);
+  else if (which == 1) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, amk_agent::agent_s2_kernel<8>, amk_agent::NT, 0);
+  else if (which == 2) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, amk_agent::agent_s2_bwd_kernel<8>, amk_agent::NT, 0);
+  else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, amk_agent::agent_s1_bwd_kernel<8>, amk_agent::NT, 0);
+  return e == hipSuccess ? n : -(int)e;
+}
+
+#ifdef AMK_AGENT_STAMPS
+extern "C" int amk_debug_agent_set_stamps(void* buf) {
+  unsigned long long* b = static_cast<unsigned long long*>(buf);
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(amk_agent::g_stamps), &b, sizeof(b));
+}
+#endif

@@ -214,6 +214,39 @@ def bf16_attention_block(B, dev, iters):
                                  "what": "max |bf16 - f32| / max |f32| of the attention core on the same bf16-rounded operands"}}
 
 
+def agent_block(dev, iters, batch=64):
+    """Secondary, informational: the AgentAttention core (models/agent_attention.py:55-73; dim 384, 6 heads x 64, 1024
+    tokens, 6 agents per head) forward and backward at batch 64, HBM-bound: algorithmic bytes 16*B*h*T*d forward (q, k,
+    v read, o written) and 28*B*h*T*d backward (q, k, v, dO read, dq, dk, dv written), against the HBM peak and
+    against the copy bandwidth measured on this box by a device-to-device copy of the same size."""
+    from amk import ops
+    from amk.models import AgentAttention
+
+    torch.manual_seed(0)
+    h, d, T = 6, 64, 1024
+    ag = AgentAttention(h * d, h, d).to(dev)
+    qkv = torch.randn(batch, T, 3 * h * d, device=dev, requires_grad=True)
+    co = torch.randn(batch, T, h * d, device=dev)
+    cw, cb = ag.dwc[1].weight, ag.dwc[1].bias
+    core = lambda: ops.agent_attention(qkv, cw, cb, h, d, ag.pool_size, ag.scale)
+    t_f = time_launches(core, iters)
+    t_fb = time_launches(lambda: torch.autograd.grad(core(), [qkv], co), iters)
+    t_b = t_fb - t_f
+    src = torch.empty(batch * T * h * d * 2, device=dev)   # 8 B per element moved: half of the forward's bytes
+    dst = torch.empty_like(src)
+    t_c = time_launches(lambda: dst.copy_(src), iters)
+    copy_gbs = 2.0 * src.numel() * 4 / t_c / 1e9
+    unit = float(batch * h * T * d)
+    rows = []
+    for name, t, nbytes in [("agent forward (pool, s1 partial, s1 combine, s2)", t_f, 16.0 * unit),
+                            ("agent backward (s2 bwd, mid, s1 bwd, pool bwd)", t_b, 28.0 * unit)]:
+        rows.append(dict(kernel=name, avg_ms=t * 1e3, bytes=nbytes, achieved=nbytes / t / 1e9, unit="GB/s", bound="hbm",
+                         frac_of_hbm_peak=nbytes / t / 1e9 / HBM_PEAK_GBS, frac_of_measured_copy=nbytes / t / 1e9 / copy_gbs))
+    del ag, qkv, co, src, dst
+    return {"workload": f"AgentAttention core, batch {batch}, 6 heads x 64, 1024 tokens, 6 agents, f32",
+            "measured_copy_gbs": copy_gbs, "kernels": rows}
+
+
 def vitmoe_block(dev, batch=64, steps=3):
     """Secondary, informational: BASELINE.json configs[3] (ViTMoE dim 1024, patch 32, depth 6, 32 experts top-2,
     SwitchHead h 8) forward + backward at batch 64, with HIP events around every routed-expert launch.
@@ -468,6 +501,10 @@ def main():
     if rank == 0 and world == 1 and not args.no_kernels and not args.no_variants:
         vitmoe = vitmoe_block(dev)
         note("ViTMoE block done")
+    agent = None
+    if rank == 0 and world == 1 and not args.no_kernels and not args.no_variants:
+        agent = agent_block(dev, args.kernel_iters)
+        note("AgentAttention block done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import train_step_cpu
@@ -545,6 +582,8 @@ def main():
             line["kernels_microbench"] = kernels
         if vitmoe:
             line["kernels_vitmoe"] = vitmoe
+        if agent:
+            line["kernels_agent"] = agent
         if cpu:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
