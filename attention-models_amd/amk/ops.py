@@ -152,7 +152,7 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=False):
     x6 = ATTENTION_FORWARD == "bf16x6" and D == 64  # head dims 32 / 128 run the plain f32 kernels
     ws = torch.empty((L.amk_attn_fwd_x6_ws_bytes(B, H, J),), device=q.device, dtype=torch.uint8) if x6 else None
     scores = None
-    if (keep_scores and D == 64 and not x6 and causal_mask is None and ATTENTION_KEEP_SCORES
+    if (keep_scores and D == 64 and not x6 and ATTENTION_KEEP_SCORES
             and not ATTENTION_BACKWARD_TWO_KERNEL):
         nbytes = L.amk_attn_scores_bytes(B, H, I, J)
         if nbytes <= ATTENTION_KEEP_SCORES_MAX_BYTES and _kept_scores_bytes[0] + nbytes <= _keep_budget(q.device):

@@ -48,7 +48,9 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 //     1 = plain stores -- of dq itself when the workgroup holds every key of its (batch, head) (J <= 32 NW: no
 //         atomics, no memset), else of this key block's partial into p.dq_part[kb], summed in key-block order
 //         by attn_bwd_dq_reduce_kernel: bitwise reproducible.
-template <int NW, bool KEPT, int DQ>
+// CAUSAL: p.causal_mask, an (I, J) byte mask shared by batch and heads (models/softmax_attention.py:62-66): a non-zero
+// byte puts the fill value in place of the score (its dS is 0, its P still feeds dV), as the forward does
+template <int NW, bool KEPT, int DQ, bool CAUSAL>
 __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p) {
   using G = FusedGeom<NW>;
   constexpr int NT = G::NT, KB = G::KB, DS_STRIDE = G::DS_STRIDE, KPG = G::KPG;
@@ -90,7 +92,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
   float kfill = 0.f;  // 0 keep, -1e9*log2e masked key, -inf beyond the sequence
   if (!kvalid) kfill = -INFINITY;
   else if (p.key_mask && p.key_mask[(int64_t)b * p.J + kj] == 0) kfill = AMK_FILL_MASKED;
-  const bool plain = __all(kfill == 0.f);  // wave-uniform: none of this wave's keys is filled
+  const bool plain = !CAUSAL && __all(kfill == 0.f);  // wave-uniform: none of this wave's scores is filled
+  // CAUSAL: this lane's key column of the mask, one byte per query row of its 16 registers; the bytes of the coming
+  // tile are requested a tile ahead (unconditional loads at clamped rows: no branch around memory instructions)
+  const uint8_t* cm_col = CAUSAL ? p.causal_mask + min(kj, p.J - 1) : nullptr;
+  unsigned cm_raw[16];
+  auto load_cmask = [&](int i0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) cm_raw[r] = cm_col[(int64_t)min(i0 + acc_row(r, hf), p.I - 1) * p.J];
+  };
 
   // K rows of the whole workgroup -> LDS once (B operand of the dQ product, and of S when it is recomputed)
   {
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
   gload.seek(rot, p.dos.st, tid);
   prefetch(rot * TQ);
   if (KEPT) load_scores(rot);
+  if (CAUSAL) load_cmask(rot * TQ);
   __syncthreads();  // the K block is in LDS
   commit();
   __syncthreads();
@@ -261,7 +272,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
         }
       }
     } else {
-      const bool filled = kfill != 0.f;
+      unsigned cbits = 0xffffu;   // bit r: the score of register r is kept
+      if (CAUSAL) {
+        cbits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cbits |= (cm_raw[r] == 0 ? 1u : 0u) << r;   // (a non-zero byte masks)
+      }
+      const float fillv = kfill != 0.f ? kfill : AMK_FILL_MASKED;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const float4 m4 = ld4(&Ms[8 * g + 4 * hf]);
@@ -270,7 +287,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float tt = filled ? kfill : s[r];
+          const bool filled = kfill != 0.f || !((cbits >> r) & 1u);
+          const float tt = filled ? fillv : s[r];
           const float pr = __builtin_amdgcn_exp2f(tt - f4(m4, e)) * f4(l4, e);
           s[r] = pr;
           dp[r] = filled ? 0.f : pr * (dp[r] - f4(d4, e));
@@ -287,6 +305,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
       load_scores(tile_of(min(t + 1, ntile - 1)));
       __builtin_amdgcn_sched_barrier(0);  // issued HERE: the compiler otherwise sinks them below the MFMAs
     }
+    if (CAUSAL) load_cmask(tile_of(min(t + 1, ntile - 1)) * TQ);
 
     // ---- dV^T += dO^T P ; dK^T += (q*scale*log2e)^T dS   (2 x 32 MFMAs)
 #pragma unroll
@@ -379,10 +398,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_reduce_kernel(const float* __
   }
 }
 
-template <int NW, bool KEPT, int DQ>
-static bool launch_variant(BwdParams p, hipStream_t st) {
+template <int NW, bool KEPT, int DQ, bool CAUSAL>
+static bool launch_variant_c(BwdParams p, hipStream_t st) {
   using G = FusedGeom<NW>;
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NW, KEPT, DQ>),
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_kernel<NW, KEPT, DQ, CAUSAL>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   G::LDS_FLOATS * (int)sizeof(float)) == hipSuccess;
   if (!attr_ok) return false;
@@ -390,13 +409,18 @@ static bool launch_variant(BwdParams p, hipStream_t st) {
   const int64_t ndq = (int64_t)p.B * p.I * p.H * D;
   if (DQ == 0 && hipMemsetAsync(p.dq, 0, (size_t)ndq * sizeof(float), st) != hipSuccess) return false;
   const int64_t nk = (int64_t)p.B * p.H * p.nkblk;
-  hipLaunchKernelGGL((attn_bwd_fused_kernel<NW, KEPT, DQ>), dim3((unsigned)nk), dim3(G::NT), G::LDS_FLOATS * sizeof(float), st, p);
+  hipLaunchKernelGGL((attn_bwd_fused_kernel<NW, KEPT, DQ, CAUSAL>), dim3((unsigned)nk), dim3(G::NT), G::LDS_FLOATS * sizeof(float), st, p);
   if (DQ == 1 && p.nkblk > 1) {
     const int64_t n4 = ndq / 4;
     const unsigned grid = (unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
     hipLaunchKernelGGL(attn_bwd_dq_reduce_kernel, dim3(grid), dim3(256), 0, st, p.dq_part, p.nkblk, n4, p.dq);
   }
   return true;
+}
+
+template <int NW, bool KEPT, int DQ>
+static bool launch_variant(const BwdParams& p, hipStream_t st) {
+  return p.causal_mask ? launch_variant_c<NW, KEPT, DQ, true>(p, st) : launch_variant_c<NW, KEPT, DQ, false>(p, st);
 }
 
 int fused_keys_per_wg(int J, int keys_per_wg) { return keys_per_wg ? keys_per_wg : (J >= 256 ? 256 : 128); }
@@ -406,7 +430,6 @@ int fused_keys_per_wg(int J, int keys_per_wg) { return keys_per_wg ? keys_per_wg
 // keys_per_wg: 128 (4 waves, two workgroups per CU) or 256 (8 waves, one per CU; half the dq adds);
 // 0 = pick (256 when the sequence has at least 256 keys).  p.dq_part != null: reproducible dq (DQ = 1).
 bool launch_attn_bwd_fused(const BwdParams& p, int keys_per_wg, hipStream_t st) {
-  if (p.causal_mask) return false;
   if (!(p.dqs.sh == D && p.dqs.st == (int64_t)p.H * D && p.dqs.sb == (int64_t)p.I * p.H * D)) return false;
   keys_per_wg = fused_keys_per_wg(p.J, keys_per_wg);
   const bool det = p.dq_part != nullptr;

@@ -346,3 +346,15 @@ def test_torch_deterministic_mode_selects_reproducible_backward(device, backward
         torch.use_deterministic_algorithms(False)
     assert all(torch.equal(a, b) for a, b in zip(g1, g2))
 
+
+def test_core_causal_many_tiles_ragged(device):
+    """Causal and arbitrary (I, J) masks over several 32-query tiles and key blocks, ragged ends: the one-pass backward
+    takes the mask itself (csrc/attn_bwd_fused.hip, CAUSAL) instead of falling back to the two recompute kernels."""
+    B, H, I, J = 2, 2, 300, 333
+    g = torch.Generator().manual_seed(11)
+    causal = torch.ones(I, J).triu(1).bool() | (torch.rand(I, J, generator=g) < 0.1)
+    causal[17, :] = True   # a dead row
+    km = torch.ones(B, J, dtype=torch.bool)
+    km[1, 5::7] = False
+    _core_case(device, B, H, I, J, key_mask=km, causal=causal, seed=12)
+    _core_case(device, B, H, I, J, causal=causal, seed=13)
