@@ -28,6 +28,14 @@ struct Params {
   int N, K, ntk, total, nchunk, steps_per_chunk;
 };
 
+// barrier that orders LDS only: global loads and stores in flight stay in flight (__syncthreads() drains them, which
+// would serialise the register prefetch of the step loops and the row stores of the persistent kernel's epilogue)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 __device__ __forceinline__ f32x16 zero16() {
   f32x16 z;
 #pragma unroll
@@ -40,10 +48,11 @@ __device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
 }
 // 32x32x16 operand whose contraction index is the ROW of the LDS tile, natural order: lane (col = c0 + (l & 31), half)
 // gets rows r0 + 8 half + (0..7)
+template <int STRIDE = STR>
 __device__ __forceinline__ bf16x8 tr_frag(const __bf16* img, int r0, int c0, int lane) {
   const int hf = lane >> 5, grp = (lane >> 4) & 1, q = (lane & 15) >> 2, pp = lane & 3;
-  const __bf16* a = img + (r0 + 8 * hf + q) * STR + c0 + 16 * grp + 4 * pp;
-  const bf16x4 lo = tr_read(a), hi = tr_read(a + 4 * STR);
+  const __bf16* a = img + (r0 + 8 * hf + q) * STRIDE + c0 + 16 * grp + 4 * pp;
+  const bf16x4 lo = tr_read(a), hi = tr_read(a + 4 * STRIDE);
   bf16x8 r;
 #pragma unroll
   for (int i = 0; i < 4; ++i) { r[i] = lo[i]; r[4 + i] = hi[i]; }
@@ -66,7 +75,9 @@ __global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Pa
   int64_t mend = mbeg + (int64_t)p.steps_per_chunk * BKM;
   if (mend > p.M) mend = p.M;
   const int mrows = (int)(mend - mbeg);
-  const int nk = (mrows + BKM - 1) / BKM;
+  // an even number of steps (a step of zeros at the end if need be): the two register sets then alternate without a branch
+  // in the loop -- behind a branch around memory instructions the compiler's waits stop counting and drain everything
+  const int nk = ((mrows + BKM - 1) / BKM + 1) & ~1;
 
   // staging: a 32 x 128 tile = 512 pieces of 16 B: thread -> column group cg (8 columns), rows sr and sr + 16
   const int cg = tid & 15, sr = tid >> 4;
@@ -81,12 +92,11 @@ __global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Pa
   }
   const unsigned ystep = (unsigned)(BKM * p.ldy * 2), xstep = (unsigned)(BKM * p.ldx * 2);
   struct Stg { float4 y[NP], x[NP]; };
-  auto gload = [&](Stg& g, int t) {
-    const int tt = t < nk ? t : nk - 1;
+  auto gload = [&](Stg& g, int t) {   // (steps past the chunk: rows past the descriptor's range, zeros)
 #pragma unroll
     for (int i = 0; i < NP; ++i) {
-      g.y[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, (int)(yoff[i] + (unsigned)tt * ystep), 0, 0));
-      g.x[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(xoff[i] + (unsigned)tt * xstep), 0, 0));
+      g.y[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, (int)(yoff[i] == COL_PAST ? COL_PAST : yoff[i] + (unsigned)t * ystep), 0, 0));
+      g.x[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(xoff[i] == COL_PAST ? COL_PAST : xoff[i] + (unsigned)t * xstep), 0, 0));
     }
   };
   const bool do_bias = p.dbias != nullptr && tk == 0;
@@ -117,7 +127,7 @@ __global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Pa
   gload(gb, 1);
   lstore(smem, ga, true);
   gload(ga, 2);
-  __syncthreads();
+  lds_barrier();
   auto step = [&](int t, Stg& g) {
     const __bf16* cur = smem + (t & 1) * 2 * OPER;
     __bf16* nxt = smem + ((t + 1) & 1) * 2 * OPER;
@@ -132,11 +142,11 @@ __global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Pa
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
     }
-    __syncthreads();
+    lds_barrier();
   };
   for (int t = 0; t < nk; t += 2) {
     step(t, gb);
-    if (t + 1 < nk) step(t + 1, ga);
+    step(t + 1, ga);
   }
   // ---- the partial tile: rows n0 + 64 wn + 32 i + (r & 3) + 8 (r >> 2) + 4 hf, column k0 + 64 wk + 32 j + ln
   float* Cb = p.nchunk > 1 ? p.ws + (int64_t)chunk * p.N * p.K : p.c;
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Pa
     float* red = reinterpret_cast<float*>(smem);   // (the loop ended with a barrier)
 #pragma unroll
     for (int j = 0; j < 8; ++j) red[sr * 128 + 8 * cg + j] = bsum[j];
-    __syncthreads();
+    lds_barrier();
     if (tid < 128) {
       float s = 0.f;
 #pragma unroll
@@ -240,7 +250,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
     const int j = n0 + 32 * (loc >> 6) + (loc & 31);
     return j < p.H ? ((loc >> 5) & 1) * p.H + j : p.N;
   };
-  const int nk = (p.K + 31) / 32;
+  const int nk = ((p.K + 31) / 32 + 1) & ~1;   // even (see the weight-gradient kernel): a step of zeros at the end if need be
   const int mrows = (int)(p.M - m0 < 128 ? p.M - m0 : 128);
   // ---- staging
   const int ar = tid >> 2, ach = tid & 3;          // A (and NT W): pieces (row ar + 64 i, 8 k at 8 ach)
@@ -263,12 +273,12 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
   const unsigned wstep = BTR ? (unsigned)(32 * p.ldw * 2) : 64u;
   struct Stg { float4 a[2], w[2]; };
   auto gload = [&](Stg& g, int t) {
-    const int tt = t < nk ? t : nk - 1;
-    const bool kin = 32 * tt + 8 * ach < p.K;   // (K a multiple of 8: a piece is in or out)
+    const bool kin = 32 * t + 8 * ach < p.K;   // (K a multiple of 8: a piece is in or out)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      g.a[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(kin ? aoff[i] + (unsigned)tt * 64u : COL_PAST), 0, 0));
-      g.w[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)((BTR || kin) ? woff[i] + (unsigned)tt * wstep : COL_PAST), 0, 0));
+      const bool win = BTR ? (32 * t + sr + 16 * i < p.K && woff[i] != COL_PAST) : (kin && woff[i] != COL_PAST);
+      g.a[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rsrc, (int)(kin ? aoff[i] + (unsigned)t * 64u : COL_PAST), 0, 0));
+      g.w[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, (int)(win ? woff[i] + (unsigned)t * wstep : COL_PAST), 0, 0));
     }
   };
   auto lstore = [&](__bf16* stage, const Stg& g) {
@@ -290,7 +300,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
   gload(gb, 1);
   lstore(smem, ga);
   gload(ga, 2);
-  __syncthreads();
+  lds_barrier();
   auto step = [&](int t, Stg& g) {
     const __bf16* cur = smem + (t & 1) * 2 * FT;
     lstore(smem + ((t + 1) & 1) * 2 * FT, g);
@@ -310,25 +320,31 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
     }
-    __syncthreads();
+    lds_barrier();
   };
   for (int t = 0; t < nk; t += 2) {
     step(t, gb);
-    if (t + 1 < nk) step(t + 1, ga);
+    step(t + 1, ga);
   }
   // ---- epilogue: acc[i][j][r] = C[m0 + 64 wm + 32 j + ln][ncol(64 wn + 32 i + (r & 3) + 8 (r >> 2) + 4 hf)]
-  if (p.bias) {
+  if (p.bias) {   // all eight requests first (clamped addresses, no branch): one memory latency, not eight
+    float4 b4[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int n = ncol(64 * wn + 32 * i + 8 * g + 4 * hf);
-        if (n < p.N) {
-          const float4 b4 = *reinterpret_cast<const float4*>(p.bias + n);
-#pragma unroll
-          for (int j = 0; j < 2; ++j) { acc[i][j][4 * g] += b4.x; acc[i][j][4 * g + 1] += b4.y; acc[i][j][4 * g + 2] += b4.z; acc[i][j][4 * g + 3] += b4.w; }
-        }
+        b4[i][g] = *reinterpret_cast<const float4*>(p.bias + (n < p.N ? n : 0));
+        if (n >= p.N) b4[i][g] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          acc[i][j][4 * g] += b4[i][g].x; acc[i][j][4 * g + 1] += b4[i][g].y; acc[i][j][4 * g + 2] += b4[i][g].z; acc[i][j][4 * g + 3] += b4[i][g].w;
+        }
   }
   __bf16* ot = smem;   // [128][OSTR] (the loop ended with a barrier)
   auto put_tile = [&](int nblocks) {   // the accumulators (n blocks 0..nblocks-1) as bf16 into the LDS tile
@@ -349,7 +365,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
   };
   if (EPI == 0 || (EPI == 1 && p.c)) {
     put_tile(2);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int pc = tid + 256 * i, row = pc >> 4, loc = 8 * (pc & 15);
@@ -359,7 +375,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
   }
   if (EPI == 2) {
     put_tile(2);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll 2
     for (int i = 0; i < 8; ++i) {
       const int pc = tid + 256 * i, row = pc >> 4, loc = 8 * (pc & 15);
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
     }
   }
   if (EPI == 1) {
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -391,7 +407,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
         acc[0][j][r] = a * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-a * AMK_LOG2E)) * acc[1][j][r];
       }
     put_tile(1);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pc = tid + 256 * i, row = pc >> 3, loc = 8 * (pc & 7);
@@ -400,6 +416,7 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
     }
   }
 }
+
 
 }  // namespace amk_gemm16
 
@@ -426,7 +443,8 @@ static int chunks_for(int64_t M, int N, int K, int* spc) {
   static int wgs = 0;
   if (wgs == 0) {
     const char* e = getenv("AMK_TN16_WGS");
-    wgs = e && atoi(e) > 0 ? atoi(e) : 2;   // workgroups per CU the grid aims at (more: more partial tiles to write and re-read)
+    wgs = e && atoi(e) > 0 ? atoi(e) : 1;   // workgroups per CU the grid aims at (more: more partial tiles to write and re-read;
+                                            // measured at the ViT shapes, 1 / 2 / 4 per CU: dW12 94 / 100 / 144 us, dWo 33 / 44 / 70 us)
   }
   int64_t chunks = ((int64_t)wgs * cus) / tiles;
   if (chunks < 1) chunks = 1;
