@@ -311,20 +311,24 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   float4 piece[2];                        // two tiles in flight (a tile is ~1 us of work, a load up to 2 us away)
   float2 st_rc[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
   const int ntile = (p.I + 31) / 32;
+  const __amdgpu_buffer_rsrc_t rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rcp, 0, p.I * 8, 0x00020000);
+  // No branch around a memory instruction anywhere in the tile loop (every thread requests the row constants, rows
+  // past the sequence at a clamped address; dQ leaves through a range-checked descriptor): behind such a branch the
+  // compiler's waits stop counting and every wait drains everything in flight -- the tile's dQ stores included.
   auto prefetch = [&](int t, int slot) {
     piece[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(t_rsrc, toff + t * tstep, 0, 0));
-    if (tid < 32) {
-      const int i = t * 32 + tid;
-      st_rc[slot] = i < p.I ? rcp[i] : make_float2(-1e30f, 0.f);   // (rows past the sequence: P = 0)
-    }
+    const int i = t * 32 + (tid & 31);
+    // rows past the sequence read zeros: P = exp2(0) = 1 there, next to dO = 0 and q = 0 rows: dV, dK get nothing, dS = 0
+    st_rc[slot] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rc_rsrc, i * 8, 0, 0));
   };
   auto commit = [&](int stage, int slot) {
     __bf16* base = tiles + stage * STG + (isq ? 0 : 32 * KSTR + 32 * TSTR);
     *reinterpret_cast<float4*>(&base[prow * KSTR + pch]) = piece[slot];                  // row-read image
     *reinterpret_cast<float4*>(&base[32 * KSTR + prow * TSTR + pch]) = piece[slot];      // transposed-read image
-    if (tid < 32) {
+    {   // every thread writes the constants of row tid & 31 (sixteen copies of the same value): were it one wave only, the
+        // compiler would move the request under that condition -- a branch around a memory instruction again
       float* sb = stat + stage * 64;
-      sb[tid] = st_rc[slot].x; sb[32 + tid] = st_rc[slot].y;
+      sb[tid & 31] = st_rc[slot].x; sb[32 + (tid & 31)] = st_rc[slot].y;
     }
   };
   const float c2 = p.scale * AMK_LOG2E;
@@ -342,16 +346,18 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   bf16x8 kq[BKEYS / 32];
 #pragma unroll
   for (int ks = 0; ks < BKEYS / 32; ++ks) kq[ks] = tr_frag16(Kt, TSTR, 32 * ks, 16 * dblk, lane);
+  const __amdgpu_buffer_rsrc_t dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dqp, 0, (int)(((int64_t)(p.I - 1) * p.H * 64 + 64) * 4), 0x00020000);
   auto dq_tile = [&](int tt) {
     const __bf16* img = dSs + (tt & 1) * BKEYS * DSTR;
     // the dQ^T block (dims x queries), so that a lane ends with four consecutive dims of ONE query: a 16-byte store
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < BKEYS / 32; ++ks) acc = mfma16(kq[ks], tr_frag16(img, DSTR, 32 * ks, 16 * qblk, lane), acc);
-    const int i = tt * 32 + 16 * qblk + (lane & 15);
-    if ((A16_ABLATE & 1) ? acc[0] == 12345.f : i < p.I)
-      *reinterpret_cast<float4*>(dqp + (int64_t)i * p.H * 64 + 16 * dblk + 4 * (lane >> 4)) =
-          make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+    const int i = tt * 32 + 16 * qblk + (lane & 15);   // (tile -1 and rows past the sequence: outside the descriptor, dropped)
+    const float4 o = make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
+    if (!(A16_ABLATE & 1))
+      __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, o), dq_rsrc,
+                                             (i * p.H * 64 + 16 * dblk + 4 * (lane >> 4)) * 4, 0, 0);
   };
   auto tile_step = [&](int t, int slot) {   // slot: where tile t + 1 waits in registers
     const int sg = t & 1;
@@ -379,7 +385,7 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
     }
     // ---- dQ of the previous tile (32 queries x 64 dims) = dS (32 x 256 keys) K (256 x 64): issued here, behind the
     //      S / dP chains in the matrix pipe, so that it runs under the exp work below
-    if (t > 0 && !(A16_ABLATE & 2)) dq_tile(t - 1);
+    if (!(A16_ABLATE & 2)) dq_tile(t - 1);   // (t = 0: an image nobody wrote, rows -32..-1: every store is dropped)
     // ---- P = exp2(c2 S'), dS / scale = P dP' (the scale goes onto dK and dQ where they are stored)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -409,15 +415,16 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
       dk0 = mfmab(tr_frag(Qtr, TSTR, u, 0, lane), db, dk0);
       dk1 = mfmab(tr_frag(Qtr, TSTR, u, 32, lane), db, dk1);
     }
-    if (t + 1 < ntile) commit((t + 1) & 1, slot);
+    commit((t + 1) & 1, slot);   // (past the last tile: zeros nobody reads)
     prefetch(t + 3, slot);
     __syncthreads();   // this tile's dS rows are in LDS, the next tile's images and statistics in place
   };
-  for (int t = 0; t < ntile; t += 2) {
+  const int ntile2 = (ntile + 1) & ~1;   // an even count: a tile past the sequence has q = 0, dO = 0 (dS = 0, nothing added)
+  for (int t = 0; t < ntile2; t += 2) {
     tile_step(t, 1);
-    if (t + 1 < ntile) tile_step(t + 1, 0);
+    tile_step(t + 1, 0);
   }
-  dq_tile(ntile - 1);
+  dq_tile(ntile2 - 1);
   if (kvalid) {
     __bf16* kp = p.dk + (int64_t)b * p.dks.sb + (int64_t)key * p.dks.st + (int64_t)h * p.dks.sh + 4 * hf;
     __bf16* vp = p.dv + (int64_t)b * p.dvs.sb + (int64_t)key * p.dvs.st + (int64_t)h * p.dvs.sh + 4 * hf;
