@@ -63,6 +63,25 @@ struct BwdParams {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ float4 f4(float x) { return make_float4(x, x, x, x); }
+// Global rows through buffer descriptors with the validity folded into the OFFSET (an invalid row gets an offset past
+// the descriptor's range: the load returns zeros, the store is dropped).  `cond ? *ptr : 0` compiles to a branch
+// around the load, and behind such a branch every wait drains everything in flight: a tile's eight row requests
+// became eight serial round trips (5.5 us to stage 32 KB; tools/scratch/stamps_agent.py).
+constexpr unsigned PAST = 0x80000000u;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab(const float* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7ffffffe, 0x00020000);
+}
+__device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+}
+__device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)off, 0, 0);
+}
+// byte offset of row t (channels c4..) in a (T, D) view with row stride st, or PAST
+__device__ __forceinline__ unsigned row_off(int t, int T, int64_t st, int c4) {
+  return (t >= 0 && t < T) ? (unsigned)(((int64_t)t * st + c4) * 4) : PAST;
+}
 __device__ __forceinline__ void fma4(float4& a, float s, const float4& x) {
   a.x += s * x.x; a.y += s * x.y; a.z += s * x.z; a.w += s * x.w;
 }
@@ -82,22 +101,21 @@ __host__ __device__ __forceinline__ int bin_hi(int i, int T, int P) { return (in
 // 16 lanes per 256-byte row, 16 rows per pass: coalesced b128 loads, conflict-free LDS writes.
 __device__ __forceinline__ void stage_rows(float* tile, const float* base, int64_t st, int t0, int T, int tid) {
   const int c4 = (tid & 15) * 4;
+  const __amdgpu_buffer_rsrc_t rs = slab(base);
+  float4 pc[CH / (NT / 16)];
 #pragma unroll
-  for (int r0 = 0; r0 < CH; r0 += NT / 16) {
-    const int r = r0 + (tid >> 4), t = t0 + r;
-    st4(tile + r * TS + c4, t < T ? ld4(base + (int64_t)t * st + c4) : f4(0.f));
-  }
+  for (int j = 0; j < CH / (NT / 16); ++j) pc[j] = bld4(rs, row_off(t0 + (NT / 16) * j + (tid >> 4), T, st, c4));   // all in flight
+#pragma unroll
+  for (int j = 0; j < CH / (NT / 16); ++j) st4(tile + ((NT / 16) * j + (tid >> 4)) * TS + c4, pc[j]);
 }
 // the same in two halves: request the pieces (registers), put them into the tile later -- the second tile of a kernel
 // is in flight while the first one is worked on
 constexpr int NPIECE = CH / (NT / 16);
 __device__ __forceinline__ void fetch_rows(float4 (&pc)[NPIECE], const float* base, int64_t st, int t0, int T, int tid) {
   const int c4 = (tid & 15) * 4;
+  const __amdgpu_buffer_rsrc_t rs = slab(base);
 #pragma unroll
-  for (int j = 0; j < NPIECE; ++j) {
-    const int t = t0 + (NT / 16) * j + (tid >> 4);
-    pc[j] = t < T ? ld4(base + (int64_t)t * st + c4) : f4(0.f);
-  }
+  for (int j = 0; j < NPIECE; ++j) pc[j] = bld4(rs, row_off(t0 + (NT / 16) * j + (tid >> 4), T, st, c4));
 }
 __device__ __forceinline__ void put_rows(float* tile, const float4 (&pc)[NPIECE], int tid) {
   const int c4 = (tid & 15) * 4;
@@ -107,10 +125,11 @@ __device__ __forceinline__ void put_rows(float* tile, const float4 (&pc)[NPIECE]
 // tile[CH][TS] -> rows [t0, min(t0+CH, T)) of a (T, D) view
 __device__ __forceinline__ void unstage_rows(const float* tile, float* base, int64_t st, int t0, int T, int tid) {
   const int c4 = (tid & 15) * 4;
+  const __amdgpu_buffer_rsrc_t rs = slab(base);
 #pragma unroll
   for (int r0 = 0; r0 < CH; r0 += NT / 16) {
-    const int r = r0 + (tid >> 4), t = t0 + r;
-    if (t < T) st4(base + (int64_t)t * st + c4, ld4(tile + r * TS + c4));
+    const int r = r0 + (tid >> 4);
+    bst4(rs, row_off(t0 + r, T, st, c4), ld4(tile + r * TS + c4));
   }
 }
 // phase A: thread (tok, half) owns channels [32*half, 32*half+32) of token tok
@@ -208,10 +227,10 @@ __global__ __launch_bounds__(NT) void agent_s1_partial_kernel(Params p) {
   // barriers in between order LDS only
   const int sub = tid >> 4, c4 = (tid & 15) * 4;
   float4 vrow[CH / (NT / 16)];
+  {
+    const __amdgpu_buffer_rsrc_t vrs = slab(vb);
 #pragma unroll
-  for (int j = 0; j < CH / (NT / 16); ++j) {
-    const int t = t0 + (NT / 16) * j + sub;
-    vrow[j] = t < T ? ld4(vb + (int64_t)t * p.vs.st + c4) : f4(0.f);
+    for (int j = 0; j < CH / (NT / 16); ++j) vrow[j] = bld4(vrs, row_off(t0 + (NT / 16) * j + sub, T, p.vs.st, c4));
   }
   lds_barrier();
   {  // phase A: two threads per key
@@ -347,10 +366,10 @@ __global__ __launch_bounds__(NT) void agent_s2_kernel(Params p) {
   // nine.  The first rows of the window are requested now and arrive under phase A (LDS-only barriers in between).
   constexpr int RPG = CH / (NT / 16);   // rows per group
   const int grp = tid >> 4, c4 = (tid & 15) * 4;
-  const float* vbatch = p.v + (int64_t)w.b * p.vs.sb;
+  const __amdgpu_buffer_rsrc_t vrs = slab(p.v + (int64_t)w.b * p.vs.sb);
   auto ldv = [&](int a, int t) {   // value row of head h + a - 1 at token t, channels c4..c4+3; zero padding
     const int h2 = w.h + a - 1;
-    return (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? ld4(vbatch + (int64_t)h2 * p.vs.sh + (int64_t)t * p.vs.st + c4) : f4(0.f);
+    return bld4(vrs, (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? (unsigned)(((int64_t)h2 * p.vs.sh + (int64_t)t * p.vs.st + c4) * 4) : PAST);
   };
   const int tfirst = t0 + RPG * grp;
   float4 win[3][4];   // [head offset][token slot]: tokens t-1, t, t+1 and the prefetched t+2
@@ -385,7 +404,7 @@ __global__ __launch_bounds__(NT) void agent_s2_kernel(Params p) {
     const float4 cb = ld4(p.convb + c4);
 #pragma unroll
     for (int i = 0; i < PM; ++i) var[i] = (i < P) ? ld4(p.vagent + (w.bh * P + i) * D + c4) : f4(0.f);
-    float* ob = p.o + (int64_t)w.b * p.os.sb + (int64_t)w.h * p.os.sh;
+    const __amdgpu_buffer_rsrc_t ors = slab(p.o + (int64_t)w.b * p.os.sb + (int64_t)w.h * p.os.sh);
 #pragma unroll
     for (int j = 0; j < RPG; ++j) {
       const int r = RPG * grp + j, t = t0 + r;
@@ -397,11 +416,11 @@ __global__ __launch_bounds__(NT) void agent_s2_kernel(Params p) {
 #pragma unroll
       for (int i = 0; i < PM; ++i)
         if (i < P) fma4(o, S[i * CH + r], var[i]);
-      if (t < T) st4(ob + (int64_t)t * p.os.st + c4, o);
+      bst4(ors, row_off(t, T, p.os.st, c4), o);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         win[a][0] = win[a][1]; win[a][1] = win[a][2]; win[a][2] = win[a][3];
-        win[a][3] = (j + 3 <= RPG) ? ldv(a, t + 3) : f4(0.f);   // (row t+3 is the last one the group's window needs)
+        win[a][3] = ldv(a, (j + 3 <= RPG) ? t + 3 : -1);   // (row t+3 is the last one the group's window needs)
       }
     }
   }
@@ -440,11 +459,11 @@ __global__ __launch_bounds__(NT) void agent_s2_bwd_kernel(BwdParams p) {
   // flight; its first rows are requested here, a whole phase early
   constexpr int RPG = CH / (NT / 16);
   const int grp = tid >> 4, c4 = (tid & 15) * 4;
+  const __amdgpu_buffer_rsrc_t vrs = slab(vbatch), grs = slab(gb), qrs = slab(qb);
   auto ldv = [&](int a, int t) {
     const int h2 = h + a - 1;
-    return (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? ld4(vbatch + (int64_t)h2 * p.vs.sh + (int64_t)t * p.vs.st + c4) : f4(0.f);
+    return bld4(vrs, (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? (unsigned)(((int64_t)h2 * p.vs.sh + (int64_t)t * p.vs.st + c4) * 4) : PAST);
   };
-  auto ldrow = [&](const float* base, int64_t st, int t) { return t < T ? ld4(base + (int64_t)t * st + c4) : f4(0.f); };
   const int tfirst = t0 + RPG * grp;
   float4 win[3][4], gq[2][3];   // value window [head offset][t-1, t, t+1, t+2]; dO / q rows [t, t+1, t+2]
 #pragma unroll
@@ -452,7 +471,7 @@ __global__ __launch_bounds__(NT) void agent_s2_bwd_kernel(BwdParams p) {
     win[a][0] = ldv(a, tfirst - 1); win[a][1] = ldv(a, tfirst); win[a][2] = ldv(a, tfirst + 1); win[a][3] = ldv(a, tfirst + 2);
   }
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { gq[0][k] = ldrow(gb, p.dos.st, tfirst + k); gq[1][k] = ldrow(qb, p.qs.st, tfirst + k); }
+  for (int k = 0; k < 3; ++k) { gq[0][k] = bld4(grs, row_off(tfirst + k, T, p.dos.st, c4)); gq[1][k] = bld4(qrs, row_off(tfirst + k, T, p.qs.st, c4)); }
   lds_barrier();
   AG_STAMP(1);
   {  // phase A: two threads per token
@@ -539,12 +558,12 @@ __global__ __launch_bounds__(NT) void agent_s2_bwd_kernel(BwdParams p) {
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         win[a][0] = win[a][1]; win[a][1] = win[a][2]; win[a][2] = win[a][3];
-        win[a][3] = (j + 3 <= RPG) ? ldv(a, t + 3) : f4(0.f);
+        win[a][3] = ldv(a, (j + 3 <= RPG) ? t + 3 : -1);
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         gq[k][0] = gq[k][1]; gq[k][1] = gq[k][2];
-        gq[k][2] = (j + 3 < RPG) ? ldrow(k == 0 ? gb : qb, k == 0 ? p.dos.st : p.qs.st, t + 3) : f4(0.f);
+        gq[k][2] = bld4(k == 0 ? grs : qrs, (j + 3 < RPG) ? row_off(t + 3, T, k == 0 ? p.dos.st : p.qs.st, c4) : PAST);
       }
     }
   }
@@ -696,9 +715,10 @@ __global__ __launch_bounds__(NT) void agent_s1_bwd_kernel(BwdParams p) {
 #pragma unroll
     for (int i = 0; i < PM; ++i) { acca[i] = f4(0.f); dva[i] = (i < P) ? ld4(&dVas[i * D + c4]) : f4(0.f); }
     // dv[h, t] += sum_{a, b} w[a][b] dO[h - (a - 1), t - (b - 1)]: window slot s holds dO[., t - 1 + s] of head h + 1 - a
+    const __amdgpu_buffer_rsrc_t grs = slab(gbatch), krs = slab(kb), dvrs = slab(dvb);
     auto ldg = [&](int a, int t) {
       const int h2 = h - (a - 1);
-      return (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? ld4(gbatch + (int64_t)h2 * p.dos.sh + (int64_t)t * p.dos.st + c4) : f4(0.f);
+      return bld4(grs, (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? (unsigned)(((int64_t)h2 * p.dos.sh + (int64_t)t * p.dos.st + c4) * 4) : PAST);
     };
     const int tfirst = t0 + RPG * grp;
     float4 win[3][4], krow[3];
@@ -707,7 +727,7 @@ __global__ __launch_bounds__(NT) void agent_s1_bwd_kernel(BwdParams p) {
       win[a][0] = ldg(a, tfirst - 1); win[a][1] = ldg(a, tfirst); win[a][2] = ldg(a, tfirst + 1); win[a][3] = ldg(a, tfirst + 2);
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) krow[k] = tfirst + k < T ? ld4(kb + (int64_t)(tfirst + k) * p.ks.st + c4) : f4(0.f);
+    for (int k = 0; k < 3; ++k) krow[k] = bld4(krs, row_off(tfirst + k, T, p.ks.st, c4));
 #pragma unroll 1
     for (int j = 0; j < RPG; ++j) {
       const int r = RPG * grp + j, t = t0 + r;
@@ -724,14 +744,14 @@ __global__ __launch_bounds__(NT) void agent_s1_bwd_kernel(BwdParams p) {
           fma4(dvv, S[i * CH + r], dva[i]);
         }
       }
-      if (t < T) st4(dvb + (int64_t)t * p.dvs.st + c4, dvv);
+      bst4(dvrs, row_off(t, T, p.dvs.st, c4), dvv);
 #pragma unroll
       for (int a = 0; a < 3; ++a) {
         win[a][0] = win[a][1]; win[a][1] = win[a][2]; win[a][2] = win[a][3];
-        win[a][3] = (j + 3 <= RPG) ? ldg(a, t + 3) : f4(0.f);
+        win[a][3] = ldg(a, (j + 3 <= RPG) ? t + 3 : -1);
       }
       krow[0] = krow[1]; krow[1] = krow[2];
-      krow[2] = (j + 3 < RPG && t + 3 < T) ? ld4(kb + (int64_t)(t + 3) * p.ks.st + c4) : f4(0.f);
+      krow[2] = bld4(krs, (j + 3 < RPG) ? row_off(t + 3, T, p.ks.st, c4) : PAST);
     }
   }
   __syncthreads();  // the dk rows have left the tile
