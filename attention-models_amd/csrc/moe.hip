@@ -270,22 +270,30 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
 
   // staging: rows sr + 32*j, 4 floats at column sc
   const int sr = tid >> 3, sc = (tid & 7) * 4;
-  const float* arow[2];
-  const float* wrow[2 * NB];
+  // operands through buffer descriptors with the validity folded into the offset (absent pairs, rows past N, the K
+  // tail: an offset past the range reads zeros): `cond ? *p : 0` compiles to a branch around the load, and behind a
+  // branch around a memory instruction every wait drains everything in flight
+  constexpr unsigned PASTO = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7ffffffe, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, 0x7ffffffe, 0x00020000);
+  unsigned aoffs[2], woffs[2 * NB];   // (the host checks that A and one expert's weights span < 2 GiB)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int pp = prow[sr + 32 * j];
-    arow[j] = pp >= 0 ? g.A + (int64_t)(pp / g.a_div) * g.lda : nullptr;
+    aoffs[j] = pp >= 0 ? (unsigned)(((int64_t)(pp / g.a_div) * g.lda + sc) * 4) : PASTO;
   }
 #pragma unroll
-  for (int j = 0; j < 2 * NB; ++j) wrow[j] = (n0 + sr + 32 * j < g.N) ? We + (int64_t)(n0 + sr + 32 * j) * g.Kd : nullptr;
+  for (int j = 0; j < 2 * NB; ++j)
+    woffs[j] = (n0 + sr + 32 * j < g.N) ? (unsigned)(((int64_t)(n0 + sr + 32 * j) * g.Kd + sc) * 4) : PASTO;
   float4 ast[2], wst[2 * NB];
-  auto prefetch = [&](int k0) {
+  auto prefetch = [&](int k0) {   // (k0 past the contraction: every piece reads zeros)
     const bool kin = k0 + sc < g.Kd;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) ast[j] = (arow[j] && kin) ? ld4(arow[j] + k0 + sc) : zero4();
+    for (int j = 0; j < 2; ++j)
+      ast[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)((kin && aoffs[j] != PASTO) ? aoffs[j] + 4u * k0 : PASTO), 0, 0));
 #pragma unroll
-    for (int j = 0; j < 2 * NB; ++j) wst[j] = (wrow[j] && kin) ? ld4(wrow[j] + k0 + sc) : zero4();
+    for (int j = 0; j < 2 * NB; ++j)
+      wst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)((kin && woffs[j] != PASTO) ? woffs[j] + 4u * k0 : PASTO), 0, 0));
   };
   auto commit = [&]() {
 #pragma unroll
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
     __syncthreads();
     commit();
     __syncthreads();
-    if (k0 + 32 < g.Kd) prefetch(k0 + 32);
+    prefetch(k0 + 32);
     if (!rows_here) continue;  // a tail tile with at most 32 pairs: this wave's row half is empty
     const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
     const float* wr = &Ws[(32 * NB * wn + ln) * LS + 16 * hf];
@@ -748,7 +756,12 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
-  if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
+  __shared__ float srow[64];   // the rows' scale factors: one request per row here, not sixteen serial ones per lane at the end
+  if (tid < 64) {
+    const int pp = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
+    prow[tid] = pp;
+    srow[tid] = (pp >= 0 && g.scale) ? g.scale[pp] : 1.f;
+  }
   __syncthreads();
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
 
@@ -756,21 +769,28 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
   constexpr int TPR = BC / 4;                        // threads per W row (16 B each)
   constexpr int RPP = 256 / TPR;                     // W rows per pass
   const int wrow_ = tid / TPR, wc = (tid % TPR) * 4; // W: rows wrow_ + RPP*j (n); cols wc (kk)
-  const float* arow[2];
+  // operands through buffer descriptors, validity folded into the offset (see grouped_nt_kernel)
+  constexpr unsigned PASTO = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7ffffffe, 0x00020000);
+  const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, 0x7ffffffe, 0x00020000);
+  unsigned aoffs[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int pp = prow[sr + 32 * j];
-    arow[j] = pp >= 0 ? g.A + (int64_t)(pp / g.a_div) * g.lda : nullptr;
+    aoffs[j] = pp >= 0 ? (unsigned)(((int64_t)(pp / g.a_div) * g.lda + sc) * 4) : PASTO;
   }
   const bool cin = c0 + wc < g.Kd;
   float4 ast[2], wst[32 / RPP];
-  auto prefetch = [&](int nb) {
+  auto prefetch = [&](int nb) {   // (nb past the contraction: every piece reads zeros)
     const bool nin = nb + sc < g.N;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) ast[j] = (arow[j] && nin) ? ld4(arow[j] + nb + sc) : zero4();
+    for (int j = 0; j < 2; ++j)
+      ast[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)((nin && aoffs[j] != PASTO) ? aoffs[j] + 4u * nb : PASTO), 0, 0));
 #pragma unroll
-    for (int j = 0; j < 32 / RPP; ++j)
-      wst[j] = (cin && nb + wrow_ + RPP * j < g.N) ? ld4(We + (int64_t)(nb + wrow_ + RPP * j) * g.Kd + c0 + wc) : zero4();
+    for (int j = 0; j < 32 / RPP; ++j) {
+      const int n = nb + wrow_ + RPP * j;
+      wst[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(w_rs, (int)((cin && n < g.N) ? (unsigned)(((int64_t)n * g.Kd + c0 + wc) * 4) : PASTO), 0, 0));
+    }
   };
   auto commit = [&]() {
 #pragma unroll
@@ -786,7 +806,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
     __syncthreads();
     commit();
     __syncthreads();
-    if (nb + 32 < g.N) prefetch(nb + 32);
+    prefetch(nb + 32);
     if (!rows_here) continue;  // a tail tile with at most 32 pairs: this wave's row half is empty
     const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
     const float* wc_ = &Ws[(16 * hf) * WS + 32 * NB * wn + ln];
@@ -807,7 +827,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int p = prow[32 * wm + acc_row(r, hf)];
-        if (p >= 0) g.Y[(int64_t)p * g.Kd + c] = acc[j][r] * (g.scale ? g.scale[p] : 1.f);
+        if (p >= 0) g.Y[(int64_t)p * g.Kd + c] = acc[j][r] * srow[32 * wm + acc_row(r, hf)];
       }
     }
   }
@@ -1263,7 +1283,8 @@ static int grouped_nt_impl(const char* who, const float* A, int64_t lda, int a_d
     { g.ncol = (N + 127) / 128; g.slots = wg_slots();  // grid: the bound for two-block tiles; the surplus workgroups leave at once
       hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3((unsigned)((P + 63) / 64 + E) * g.ncol + (unsigned)g.slots / 2), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else
-    { g.ncol = (N + 63) / 64; hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+    { AMK_CHECK_SUPPORTED(g.a_bytes < 0x7fff0000ll && (int64_t)N * Kd * 4 < 0x7fff0000ll, "%s: A and one expert's weights must span < 2 GiB", who);
+      g.ncol = (N + 63) / 64; hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH(who);
   return AMK_OK;
 }
@@ -1298,6 +1319,9 @@ static int grouped_nn_impl(const char* who, const float* A, int64_t lda, int a_d
   if (wide && (y_div > 0 || !getenv("AMK_MOE_NARROW"))) {
     g.ncol = (Kd + 127) / 128; g.slots = wg_slots();
     hipLaunchKernelGGL(grouped_nn_wide_kernel, dim3(mt * g.ncol + (unsigned)g.slots / 2), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  } else if (g.a_bytes >= 0x7fff0000ll || (int64_t)N * Kd * 4 >= 0x7fff0000ll) {
+    amk_set_error("%s: A and one expert's weights must span < 2 GiB", who);
+    return AMK_EUNSUPPORTED;
   } else if (Kd > 64) { g.ncol = (Kd + 127) / 128; hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else { g.ncol = 1; hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH(who);
