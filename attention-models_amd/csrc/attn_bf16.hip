@@ -83,6 +83,13 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* img, int stride, int t, 
   return cat4(tr_read(a), tr_read(a + 8 * stride));
 }
 
+// barrier that orders LDS only (global loads in flight stay in flight)
+__device__ __forceinline__ void lds_barrier_bf() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 template <int DUMMY>
 __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
@@ -143,10 +150,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
   prefetch(0);
   for (int t = 0; t < ntile; ++t) {
     const int j0 = t * 64;
-    __syncthreads();
+    lds_barrier_bf();
     commit();
-    __syncthreads();
-    if (t + 1 < ntile) prefetch(t + 1);
+    lds_barrier_bf();
+    prefetch(t + 1);   // (unconditional: a tile past the sequence is outside the descriptors and reads zeros; a branch around
+                       //  a memory instruction would make every wait of the loop a full drain)
     // ---- S^T = K Q^T: two 32-key blocks x four 16-deep steps
     f32x16 s0 = zero16(), s1 = zero16();
 #pragma unroll

@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void tn_bf16_reduce_kernel(Params p) {
 //   steps, so its prologue and epilogue are hidden by the CU's other workgroups, not by its own loop).
 //   The product is formed TRANSPOSED (W fragments as the MFMA's row operand), so a lane ends with four consecutive
 //   output columns of one row; the tile is then turned through LDS into 16-byte row pieces.
+#ifndef G16_ABLATE
+#define G16_ABLATE 0   // timing experiments only (tools/ablate_gemm_bf16.sh): 1 no epilogue, 2 no MFMAs, 4 no operand reads from LDS
+#endif
 constexpr int FSTR = 32;            // bf16 per LDS row of a [128 rows][32 k] operand tile: no padding, the four 16-byte
                                     // chunks of row r sit at chunk ^ ((r >> 2) & 3) (writes and b128 reads conflict-free)
 constexpr int FT = 32 * STR;        // elements per operand tile buffer (the [32 k][128 n] tile of the NN form; >= 128 * FSTR)
@@ -310,6 +313,11 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
       bf16x8 xf[2], wf[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
+        if (G16_ABLATE & 4) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { xf[i][e] = (__bf16)(float)(tid + e); wf[i][e] = (__bf16)(float)(lane - e); }
+          continue;
+        }
         const int sw = 8 * ((2 * s + hf) ^ ((ln >> 2) & 3));   // (row offsets 64 w + 32 i: multiples of 16, swizzle of ln)
         xf[i] = *reinterpret_cast<const bf16x8*>(&cur[(64 * wm + 32 * i + ln) * FSTR + sw]);
         wf[i] = BTR ? tr_frag(cur + FT, 16 * s, 64 * wn + 32 * i, lane)
@@ -318,13 +326,20 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < 2; ++j) {
+          if (G16_ABLATE & 2) acc[i][j][0] += (float)wf[i][0] * (float)xf[j][1];
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
     }
     lds_barrier();
   };
   for (int t = 0; t < nk; t += 2) {
     step(t, gb);
     step(t + 1, ga);
+  }
+  if (G16_ABLATE & 1) {
+    if (acc[0][0][0] + acc[0][1][1] + acc[1][0][2] + acc[1][1][3] == 12345.f) p.c[0] = (__bf16)1.f;
+    return;
   }
   // ---- epilogue: acc[i][j][r] = C[m0 + 64 wm + 32 j + ln][ncol(64 wn + 32 i + (r & 3) + 8 (r >> 2) + 4 hf)]
   if (p.bias) {   // all eight requests first (clamped addresses, no branch): one memory latency, not eight
