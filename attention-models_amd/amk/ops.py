@@ -1298,7 +1298,9 @@ def swiglu_ffn(x, w12, b12, w3, b3):
         if _mixed_linear_ok(x, w12) and _mixed_linear_ok(x, w3) and w3.requires_grad:
             with torch.autocast("cuda", enabled=False):
                 return _SwiGLUFFNMixed.apply(x, w12, b12, w3, b3)
-        if (MIXED_WGRAD and not torch.is_grad_enabled() and x.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16
+        no_grad = not torch.is_grad_enabled() or not any(
+            t is not None and t.requires_grad for t in (x, w12, b12, w3, b3))   # (e.g. the generator's forward in the D phase)
+        if (MIXED_WGRAD and no_grad and x.is_cuda and torch.get_autocast_dtype("cuda") == torch.bfloat16
                 and w12.dtype == torch.float32 and x.dtype in (torch.float32, torch.bfloat16) and w12.shape[1] % 8 == 0 and x.numel()):
             from . import dense   # inference: the gate only, the pre-activations never reach HBM
 
