@@ -4,8 +4,8 @@
 // under cfg/vitvqgan.yaml:73).  The vendor library runs these products -- tiny outputs, a contraction over all
 // B*T rows -- at 70-300 TFLOP/s (90-150 us each at batch 32) and the bias gradients as separate reductions; they are
 // HBM-bound: every byte of dY and X has to be read once and that is all.
-//   tile 128 (n) x 128 (k), four waves as 2 x 2 of 64 x 64, v_mfma_f32_32x32x16_bf16; the M rows in chunks so that
-//   tiles x chunks fills the chip four workgroups deep; partial tiles (f32) through a workspace, summed in chunk order
+//   tile 128 (n) x 256 (k), eight waves as 2 x 4 of 64 x 64 (128 x 128, four waves, for K < 256), v_mfma_f32_32x32x16_bf16;
+//   the M rows in chunks so that tiles x chunks is one workgroup per CU; partial tiles (f32) through a workspace, summed in chunk order
 //   (bitwise reproducible); both operands are staged AS STORED -- [32 rows][128 columns] bf16, row stride 320 B -- and
 //   both MFMA operands (whose contraction index is the row) come from ds_read_b64_tr_b16, 4 rows x 64 B per
 //   half-wave on 64 distinct banks; db = column sums of the staged dY pieces (first k tile only).
@@ -59,18 +59,23 @@ __device__ __forceinline__ bf16x8 tr_frag(const __bf16* img, int r0, int c0, int
   return r;
 }
 
-// BKM: rows of the contraction per step
-template <int BKM>
-__global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Params p) {
-  constexpr int OPER = BKM * STR, NP = BKM / 16;   // elements of one operand tile; 16-byte pieces per thread and operand
-  __shared__ __attribute__((aligned(16))) __bf16 smem[2 * 2 * OPER];   // 2 stages x {Y tile, X tile}
+// NWN x NWK waves of 64 x 64: tile 64 NWN (n) x 64 NWK (k); 64 rows of the contraction per step
+template <int NWN, int NWK>
+__global__ __launch_bounds__(64 * NWN * NWK, 2) void gemm_tn_bf16_kernel(Params p) {
+  constexpr int BKM = 64, NTH = 64 * NWN * NWK, TN = 64 * NWN, TK = 64 * NWK;
+  constexpr int YSTR = TN + 32, XSTR = TK + 32;          // (TN / 2 + 16 dwords = 16 mod 64: conflict-free transposing reads)
+  constexpr int YT = BKM * YSTR, STAGE = YT + BKM * XSTR;  // elements of the Y tile / of one stage {Y tile, X tile}
+  constexpr int YCG = TN / 8, YRP = NTH / YCG, YNP = BKM / YRP;   // Y: 16-byte column groups, rows per pass, pieces per thread
+  constexpr int XCG = TK / 8, XRP = NTH / XCG, XNP = BKM / XRP;
+  static_assert(TN % 128 == 0 && TK % 128 == 0 && YNP >= 1 && XNP >= 1, "tile shape");
+  extern __shared__ __attribute__((aligned(16))) __bf16 smem[];   // 2 stages
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
-  const int wn = wave >> 1, wk = wave & 1;
+  const int wn = wave / NWK, wk = wave % NWK;
   const int u = xcd_remap(blockIdx.x, p.total);
   // unit order (n tile, chunk, k tile): the k tiles that read the same dY panel are neighbours (one XCD, one L2)
   const int tk = u % p.ntk, rest = u / p.ntk;
   const int tn = rest / p.nchunk, chunk = rest - tn * p.nchunk;
-  const int n0 = tn * 128, k0 = tk * 128;
+  const int n0 = tn * TN, k0 = tk * TK;
   const int64_t mbeg = (int64_t)chunk * p.steps_per_chunk * BKM;
   int64_t mend = mbeg + (int64_t)p.steps_per_chunk * BKM;
   if (mend > p.M) mend = p.M;
@@ -79,41 +84,42 @@ __global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Pa
   // in the loop -- behind a branch around memory instructions the compiler's waits stop counting and drain everything
   const int nk = ((mrows + BKM - 1) / BKM + 1) & ~1;
 
-  // staging: a 32 x 128 tile = 512 pieces of 16 B: thread -> column group cg (8 columns), rows sr and sr + 16
-  const int cg = tid & 15, sr = tid >> 4;
+  // staging: thread -> column group (8 columns) of each operand tile, rows sr + RP i
+  const int ycg = tid % YCG, ysr = tid / YCG, xcg = tid % XCG, xsr = tid / XCG;
   const __amdgpu_buffer_rsrc_t y_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.y + mbeg * p.ldy), 0, (int)(((int64_t)(mrows - 1) * p.ldy + p.N) * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + mbeg * p.ldx), 0, (int)(((int64_t)(mrows - 1) * p.ldx + p.K) * 2), 0x00020000);
-  const bool yok = n0 + 8 * cg < p.N, xok = k0 + 8 * cg < p.K;   // (N and K multiples of 8: a piece is in or out)
-  unsigned yoff[NP], xoff[NP];
+  const bool yok = n0 + 8 * ycg < p.N, xok = k0 + 8 * xcg < p.K;   // (N and K multiples of 8: a piece is in or out)
+  unsigned yoff[YNP], xoff[XNP];
 #pragma unroll
-  for (int i = 0; i < NP; ++i) {
-    yoff[i] = yok ? (unsigned)(((int64_t)(sr + 16 * i) * p.ldy + n0 + 8 * cg) * 2) : COL_PAST;
-    xoff[i] = xok ? (unsigned)(((int64_t)(sr + 16 * i) * p.ldx + k0 + 8 * cg) * 2) : COL_PAST;
-  }
+  for (int i = 0; i < YNP; ++i) yoff[i] = yok ? (unsigned)(((int64_t)(ysr + YRP * i) * p.ldy + n0 + 8 * ycg) * 2) : COL_PAST;
+#pragma unroll
+  for (int i = 0; i < XNP; ++i) xoff[i] = xok ? (unsigned)(((int64_t)(xsr + XRP * i) * p.ldx + k0 + 8 * xcg) * 2) : COL_PAST;
   const unsigned ystep = (unsigned)(BKM * p.ldy * 2), xstep = (unsigned)(BKM * p.ldx * 2);
-  struct Stg { float4 y[NP], x[NP]; };
+  struct Stg { float4 y[YNP], x[XNP]; };
   auto gload = [&](Stg& g, int t) {   // (steps past the chunk: rows past the descriptor's range, zeros)
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
+    for (int i = 0; i < YNP; ++i)
       g.y[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(y_rsrc, (int)(yoff[i] == COL_PAST ? COL_PAST : yoff[i] + (unsigned)t * ystep), 0, 0));
+#pragma unroll
+    for (int i = 0; i < XNP; ++i)
       g.x[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(x_rsrc, (int)(xoff[i] == COL_PAST ? COL_PAST : xoff[i] + (unsigned)t * xstep), 0, 0));
-    }
   };
   const bool do_bias = p.dbias != nullptr && tk == 0;
   float bsum[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-  auto lstore = [&](__bf16* stage, const Stg& g, bool count) {
+  auto lstore = [&](__bf16* stage, const Stg& g) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-      *reinterpret_cast<float4*>(&stage[(sr + 16 * i) * STR + 8 * cg]) = g.y[i];
-      *reinterpret_cast<float4*>(&stage[OPER + (sr + 16 * i) * STR + 8 * cg]) = g.x[i];
-      if (do_bias && count) {
+    for (int i = 0; i < YNP; ++i) {
+      *reinterpret_cast<float4*>(&stage[(ysr + YRP * i) * YSTR + 8 * ycg]) = g.y[i];
+      if (do_bias) {   // (steps past the chunk carry zeros)
         const bf16x8 v = __builtin_bit_cast(bf16x8, g.y[i]);
 #pragma unroll
         for (int j = 0; j < 8; ++j) bsum[j] += (float)v[j];
       }
     }
+#pragma unroll
+    for (int i = 0; i < XNP; ++i) *reinterpret_cast<float4*>(&stage[YT + (xsr + XRP * i) * XSTR + 8 * xcg]) = g.x[i];
   };
   f32x16 acc[2][2];
 #pragma unroll
@@ -125,18 +131,17 @@ __global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Pa
   Stg ga, gb;
   gload(ga, 0);
   gload(gb, 1);
-  lstore(smem, ga, true);
+  lstore(smem, ga);
   gload(ga, 2);
   lds_barrier();
   auto step = [&](int t, Stg& g) {
-    const __bf16* cur = smem + (t & 1) * 2 * OPER;
-    __bf16* nxt = smem + ((t + 1) & 1) * 2 * OPER;
-    lstore(nxt, g, t + 1 < nk);   // tile t+1 (loaded two steps ago) -> the other stage; then fetch tile t+3
+    const __bf16* cur = smem + (t & 1) * STAGE;
+    lstore(smem + ((t + 1) & 1) * STAGE, g);   // tile t+1 (loaded two steps ago) -> the other stage; then fetch tile t+3
     gload(g, t + 3);
 #pragma unroll
     for (int s = 0; s < BKM / 16; ++s) {
-      const bf16x8 a0 = tr_frag(cur, 16 * s, 64 * wn, lane), a1 = tr_frag(cur, 16 * s, 64 * wn + 32, lane);
-      const bf16x8 b0 = tr_frag(cur + OPER, 16 * s, 64 * wk, lane), b1 = tr_frag(cur + OPER, 16 * s, 64 * wk + 32, lane);
+      const bf16x8 a0 = tr_frag<YSTR>(cur, 16 * s, 64 * wn, lane), a1 = tr_frag<YSTR>(cur, 16 * s, 64 * wn + 32, lane);
+      const bf16x8 b0 = tr_frag<XSTR>(cur + YT, 16 * s, 64 * wk, lane), b1 = tr_frag<XSTR>(cur + YT, 16 * s, 64 * wk + 32, lane);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
@@ -165,15 +170,15 @@ __global__ __launch_bounds__(256, BKM == 32 ? 4 : 2) void gemm_tn_bf16_kernel(Pa
       }
     }
   }
-  if (do_bias) {   // fold the 16 row groups (sr) of each column group
+  if (do_bias) {   // fold the YRP row groups of each column group
     float* red = reinterpret_cast<float*>(smem);   // (the loop ended with a barrier)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) red[sr * 128 + 8 * cg + j] = bsum[j];
+    for (int j = 0; j < 8; ++j) red[ysr * TN + 8 * ycg + j] = bsum[j];
     lds_barrier();
-    if (tid < 128) {
+    if (tid < TN) {
       float s = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s += red[r * 128 + tid];
+      for (int r = 0; r < YRP; ++r) s += red[r * TN + tid];
       const int n = n0 + tid;
       if (n < p.N) (p.nchunk > 1 ? p.dbias_ws + (int64_t)chunk * p.N : p.dbias)[n] = s;
     }
@@ -437,13 +442,18 @@ __global__ __launch_bounds__(256, 4) void gemm_bf16_kernel(FParams p) {
 
 using namespace amk_gemm16;
 
-static int step_rows() {
-  static int bkm = 0;
-  if (bkm == 0) {
-    const char* e = getenv("AMK_TN16_BKM");
-    bkm = e && atoi(e) == 32 ? 32 : 64;
+// tile width along K: 256 (eight waves as 2 x 4: dY is staged once for a whole K = 256, and a CU holds two waves per SIMD at
+// one workgroup per CU) for the gradients with many tiles, else 128 (four waves): measured at the ViT shapes, 256 / 128:
+// dW12 (2736 x 256) 72 / 95 us, dW3 (256 x 1368) 49 / 51, dWkv (1024 x 256) 43 / 40, dWq 29 / 26, dWo (256 x 512) 44 / 34 --
+// with few tiles the chunks get short and the eight-wave workgroup's prologue and epilogue show.  AMK_TN16_TK overrides.
+static int tile_k(int N, int K) {
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("AMK_TN16_TK");
+    forced = e ? atoi(e) : 0;
   }
-  return bkm;
+  if (forced == 128 || forced == 256) return forced;
+  return (K >= 256 && ((N + 127) / 128) * ((K + 255) / 256) >= 12) ? 256 : 128;
 }
 
 static int chunks_for(int64_t M, int N, int K, int* spc) {
@@ -452,8 +462,9 @@ static int chunks_for(int64_t M, int N, int K, int* spc) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
   }
-  const int tiles = ((N + 127) / 128) * ((K + 127) / 128);
-  const int BKM = step_rows();
+  const int TK = tile_k(N, K);
+  const int tiles = ((N + 127) / 128) * ((K + TK - 1) / TK);
+  const int BKM = 64;
   const int64_t steps = (M + BKM - 1) / BKM;
   static int wgs = 0;
   if (wgs == 0) {
@@ -490,7 +501,7 @@ extern "C" int amk_gemm_tn_bf16(const void* y, int64_t ldy, const void* x, int64
   int spc;
   p.nchunk = chunks_for(M, N, K, &spc);
   p.steps_per_chunk = spc;
-  const int BKM = step_rows();
+  const int BKM = 64;
   AMK_CHECK_SUPPORTED((int64_t)spc * BKM * ldy * 2 < (1ll << 30) && (int64_t)spc * BKM * ldx * 2 < (1ll << 30), "amk_gemm_tn_bf16: chunk panel beyond 1 GiB");
   if (p.nchunk > 1) {
     AMK_CHECK_ARG(workspace && ws_bytes >= amk_gemm_tn_bf16_ws_bytes(M, N, K) && ((uintptr_t)workspace & 15) == 0,
@@ -498,13 +509,21 @@ extern "C" int amk_gemm_tn_bf16(const void* y, int64_t ldy, const void* x, int64
     p.ws = static_cast<float*>(workspace);
     p.dbias_ws = p.ws + (int64_t)p.nchunk * N * K;
   }
-  p.ntk = (K + 127) / 128;
+  const int TK = tile_k(N, K);
+  p.ntk = (K + TK - 1) / TK;
   const int64_t total = (int64_t)((N + 127) / 128) * p.ntk * p.nchunk;
   AMK_CHECK_SUPPORTED(total < (1ll << 31), "amk_gemm_tn_bf16: grid too large");
   p.total = (int)total;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (BKM == 32) hipLaunchKernelGGL(gemm_tn_bf16_kernel<32>, dim3((unsigned)total), dim3(256), 0, st, p);
-  else hipLaunchKernelGGL(gemm_tn_bf16_kernel<64>, dim3((unsigned)total), dim3(256), 0, st, p);
+  constexpr size_t lds4 = (size_t)2 * 64 * ((128 + 32) + (128 + 32)) * 2, lds8 = (size_t)2 * 64 * ((128 + 32) + (256 + 32)) * 2;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
+    attr_set = true;
+  }
+  if (TK == 256) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 4>), dim3((unsigned)total), dim3(512), lds8, st, p);
+  else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2>), dim3((unsigned)total), dim3(256), lds4, st, p);
   if (p.nchunk > 1) {
     int64_t blocks = ((int64_t)N * K / 4 + 255) / 256;
     if (blocks < (N + 255) / 256) blocks = (N + 255) / 256;   // (thread n also folds the bias partials of column n)
