@@ -63,6 +63,7 @@ class VQGANTrainStep:
         self.fused_optimizer = fused if fused_optimizer is None else bool(fused_optimizer)
         okw = dict(betas=betas, weight_decay=weight_decay, fused=fused)
         self._graph = None
+        self._accum_graph = None
         if self.fused_optimizer:
             # under bf16 autocast the generator's update kernel also refreshes the bf16 copies its GEMMs read
             self.g_optim = FlatAdam(self.g_red, lr=lr, betas=betas, weight_decay=weight_decay, capturable=capturable,
@@ -160,6 +161,41 @@ class VQGANTrainStep:
 
     def release_graph(self):
         self._graph = None
+        self._accum_graph = None
+
+    def capture_accumulated(self, micro_batches, warmup=2):
+        """Capture ONE optimizer step over several micro-batches (gradient accumulation: every micro-batch but the last
+        with sync=False, losses divided by their number, as accelerator.accumulate runs the reference's shipped
+        `gradient_accumulation_steps`) into a HIP graph; step_accumulated() then replays it.  Same conditions as capture()."""
+        from .graphs import GraphedStep
+
+        if not self.g_red.alone or not self.d_red.alone:
+            raise RuntimeError("VQGANTrainStep.capture_accumulated: data-parallel steps run eagerly")
+        n = len(micro_batches)
+
+        def body(*xs):
+            for x in xs[:-1]:
+                self.step_body(x, False, n, None)
+            return self.step_body(xs[-1], True, n, None)
+
+        self._accum_graph = None
+        self._accum_graph = GraphedStep(body, list(micro_batches), warmup=warmup)
+
+    def step_accumulated(self, micro_batches):
+        """One optimizer step over the micro-batches: a replay of capture_accumulated()'s graph when the shapes match, else
+        eager micro-steps."""
+        self._set_lr()
+        g = getattr(self, "_accum_graph", None)
+        if g is not None and len(micro_batches) == len(g.static_inputs) and all(
+                a.shape == b.shape for a, b in zip(micro_batches, g.static_inputs)):
+            logs = g.replay(*micro_batches)
+        else:
+            n = len(micro_batches)
+            for x in micro_batches[:-1]:
+                self.step_body(x, False, n, None)
+            logs = self.step_body(micro_batches[-1], True, n, None)
+        self.global_step += len(micro_batches)
+        return logs
 
     def _optim_step(self, opt, red, module):
         if isinstance(opt, FlatAdam):

@@ -492,6 +492,33 @@ def main():
         v16.update(bf16_attention_block(args.batch, dev, args.kernel_iters))
         variants["variant_bf16_autocast"] = v16
         note("bf16-autocast variant done")
+        # the reference's shipped schedule (cfg/vitvqgan.yaml:37,72-76): batch_size 8, gradient_accumulation_steps 2, bf16
+        # autocast -- two micro-batches of 8 per optimizer step, eager (the accumulation micro-step is not the captured one)
+        trainer.release_graph()
+        trainer.autocast = torch.bfloat16
+        img8a, img8b = imgs[:8].contiguous(), imgs[8:16].contiguous()
+
+        def shipped_step():
+            return trainer.step_accumulated([img8a, img8b])
+
+        for _ in range(2):
+            shipped_step()
+        if use_graph:
+            trainer.capture_accumulated([img8a, img8b])
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            shipped_step()
+        sync()
+        dts = time.perf_counter() - t0
+        trainer.release_graph()
+        trainer.autocast = None
+        variants["variant_shipped_schedule"] = {
+            "value": 16 * args.steps / dts, "unit": "images/s", "ms_per_optimizer_step": dts / args.steps * 1e3, "dtype": "bf16 (autocast)",
+            "what": "the reference's shipped schedule, cfg/vitvqgan.yaml:37,72-76: batch_size 8 x gradient_accumulation_steps 2 under "
+                    "bf16 autocast (two micro-batches per optimizer step, VQGANTrainStep.step_accumulated: the whole optimizer step as "
+                    "one HIP-graph replay unless --no-graph); not the headline value"}
+        note("shipped-schedule variant done")
 
     kernels = None
     if rank == 0 and not args.no_kernels:

@@ -299,3 +299,35 @@ def _graph_replay_case(device, copy, GraphedStep, ViTVQGAN, NLayerDiscriminator,
     assert c2.global_step == e2.global_step == 3
     for (n, p), q in zip(model3.named_parameters(), model4.parameters()):
         assert float((p - q).abs().max()) <= 2e-5 * max(1.0, float(p.abs().max())), n
+
+
+def test_accumulated_step_capture_matches_eager_micro_steps(device, monkeypatch):
+    """VQGANTrainStep.capture_accumulated: one optimizer step over two micro-batches (the reference's shipped
+    gradient_accumulation_steps: 2, cfg/vitvqgan.yaml:72-76, as accelerator.accumulate runs it) replayed as one HIP
+    graph gives the parameters of the eager micro-steps."""
+    import copy
+
+    from amk import ops
+    from amk.models import ViTVQGAN
+    from amk.models.discriminator import NLayerDiscriminator
+    from amk.train import VQGANTrainStep
+
+    monkeypatch.setattr(ops, "DETERMINISTIC_ATTENTION_BACKWARD", True)   # (no dq atomics: comparable to 2e-5)
+    vit = dict(dim=64, img_size=32, patch_size=8, n_heads=1, d_head=64, depth=1, mlp_dim=128, dropout=0.0)
+    torch.manual_seed(0)
+    model = ViTVQGAN(vit, dict(codebook_size=64, codebook_dim=32)).to(device)
+    discr = NLayerDiscriminator(3, 8, 3).to(device)
+    model2, discr2 = copy.deepcopy(model), copy.deepcopy(discr)
+    a, b = torch.rand(2, 3, 32, 32, device=device), torch.rand(2, 3, 32, 32, device=device)
+    eager = VQGANTrainStep(model, discr, warmup_steps=1, gp_lambda=0.0, capturable=True)
+    graphed = VQGANTrainStep(model2, discr2, warmup_steps=1, gp_lambda=0.0, capturable=True)
+    eager.step_accumulated([a, b])
+    graphed.step_accumulated([a, b])          # eager: also fixes the set of parameters with gradients
+    graphed.capture_accumulated([a, b], warmup=0)
+    for _ in range(2):
+        le, lg = eager.step_accumulated([a, b]), graphed.step_accumulated([a, b])
+        for k in le:
+            assert float((le[k] - lg[k]).abs()) <= 2e-5 * max(1.0, float(le[k].abs())), k
+    assert eager.global_step == graphed.global_step == 6
+    for (n, p), q in zip(model.named_parameters(), model2.parameters()):
+        assert float((p - q).abs().max()) <= 2e-5 * max(1.0, float(p.abs().max())), n
