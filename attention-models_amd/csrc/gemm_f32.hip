@@ -1060,7 +1060,17 @@ static int tn_chunks(const amk_gemm_desc* d, int* steps_per_chunk) {
   const int tiles = ((d->n + 127) / 128) * ((d->k + 127) / 128);
   const int64_t steps = (d->m + bk - 1) / bk;
   const int64_t min_steps = 256 / bk;  // at least 256 rows per chunk
-  int64_t chunks = wg_slots() / tiles;  // workgroup slots of the chip over the tiles
+  // workgroups the grid aims at: the chip's slots (two per CU) for gradients with many tiles, half of them for the
+  // small ones, where the f32 partial tiles (chunks x N x K, written and re-read) weigh more than the second workgroup
+  // per CU brings -- measured, 512 / 256 slots: q 121 / 109 us, kv 174 / 167, W_o 111 / 105, but w12 415 / 477, w3 210 /
+  // 229.  AMK_DENSE_TN_SLOTS overrides.
+  static int forced = -1;
+  if (forced < 0) {
+    const char* e = getenv("AMK_DENSE_TN_SLOTS");
+    forced = e && atoi(e) > 0 ? atoi(e) : 0;
+  }
+  const int slots = forced ? forced : (tiles <= 16 ? wg_slots() / 2 : wg_slots());
+  int64_t chunks = slots / tiles;  // workgroup slots over the tiles
   if (chunks < 1) chunks = 1;
   if (chunks > steps / min_steps) chunks = steps / min_steps > 0 ? steps / min_steps : 1;
   int64_t spc = (steps + chunks - 1) / chunks;
