@@ -24,6 +24,7 @@
 // bias1 / bias2 are scalars added to every score of a softmax row: the softmax is invariant
 // to them, so they do not enter the arithmetic and their gradient is exactly 0.
 #include "amk_common.h"
+#include <stdlib.h>
 
 namespace amk_agent {
 
@@ -132,6 +133,12 @@ __device__ __forceinline__ void unstage_rows(const float* tile, float* base, int
     bst4(rs, row_off(t0 + r, T, st, c4), ld4(tile + r * TS + c4));
   }
 }
+// a value moved inside a row of 16 lanes by a DPP pattern (one VALU modifier; __shfl_xor compiles to ds_bpermute_b32, an
+// LDS-crossbar round trip)
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
 // phase A: thread (tok, half) owns channels [32*half, 32*half+32) of token tok
 __device__ __forceinline__ void load_half(const float* tile, int tok, int half, float (&r)[HALF]) {
   const float* src = tile + tok * TS + HALF * half;
@@ -150,7 +157,7 @@ __device__ __forceinline__ float dot_half(const float (&r)[HALF], const float* a
     const float4 t = ld4(src + 4 * j);
     s += r[4 * j] * t.x + r[4 * j + 1] * t.y + r[4 * j + 2] * t.z + r[4 * j + 3] * t.w;
   }
-  return s + __shfl_xor(s, 1, 64);
+  return s + dpp_mov<0xB1>(s);   // quad_perm [1, 0, 3, 2]: the other half of the token
 }
 // sum over the four 16-lane row groups of a wave (phase B: lane bits 4, 5 select the token)
 __device__ __forceinline__ float4 fold_subs(float4 a) {
@@ -767,6 +774,222 @@ __global__ __launch_bounds__(NT) void agent_s1_bwd_kernel(BwdParams p) {
   for (int i = wave; i < P; i += 4) p.pa1[(cell * P + i) * D + lane] = p.scale * fold4(red, i, lane);
 }
 
+// ---------------------------------------------------------------------------------------
+// Streaming forms of the two chunk kernels of the backward (P <= 8 agents per head).  The kernels above stage a
+// chunk's rows in LDS and run two thread mappings over them (2 threads <-> token for the p-wide arithmetic, 16 lanes <->
+// row for the sums): five barrier-separated phases per workgroup, the agents re-read from LDS for every token, and
+// -- every workgroup of the chip being in the same phase at the same time -- HBM idle during the arithmetic.  Here
+// ONE mapping serves everything: 16 lanes per row (4 channels each), a 16-lane group takes CH / 16 consecutive rows
+// from load to store; the agents' channels of a lane sit in registers, a row's p scores are 4-channel partial dots
+// folded over the 16 lanes by four DPP steps, and nothing goes through LDS but the final fold of the per-group sums.
+// The convolution's weight / bias gradient moves to the stage-1 kernel, which holds the dO window anyway:
+//   dw[a][b] = sum g[h][t] v[h+a-1][t+b-1] = sum v[h'][t'] g[h'-(a-1)][t'-(b-1)]   (h' = h+a-1, t' = t+b-1).
+__device__ __forceinline__ float dot4(const float4& a, const float4& b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+// sum over the 16 lanes of a row group, every lane ends with it: four DPP moves inside the row (quad swaps, then the
+// mirrored half-row and row: after the quad steps all four lanes of a quad agree, so a mirror is as good as an xor) --
+// __shfl_xor compiles to ds_bpermute_b32, an LDS-crossbar round trip per step, 48 of them per token row here
+__device__ __forceinline__ float fold16(float x) {
+  x += dpp_mov<0xB1>(x);    // quad_perm [1, 0, 3, 2]
+  x += dpp_mov<0x4E>(x);    // quad_perm [2, 3, 0, 1]
+  x += dpp_mov<0x141>(x);   // row_half_mirror
+  x += dpp_mov<0x140>(x);   // row_mirror
+  return x;
+}
+
+template <int PM>
+__global__ __launch_bounds__(NT) void agent_s2_bwd_stream_kernel(BwdParams p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * 2 * PM * D];   // [wave][dV_agent | dA][agent][channel]
+  constexpr int RPG = CH / (NT / 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, c4 = (tid & 15) * 4;
+  const Where w = where(p.H, p.NC);
+  const int P = p.P, T = p.T, h = w.h;
+  const __amdgpu_buffer_rsrc_t qrs = slab(p.q + (int64_t)w.b * p.qs.sb + (int64_t)h * p.qs.sh);
+  const __amdgpu_buffer_rsrc_t grs = slab(p.d_o + (int64_t)w.b * p.dos.sb + (int64_t)h * p.dos.sh);
+  const __amdgpu_buffer_rsrc_t dqrs = slab(p.dq + (int64_t)w.b * p.dqs.sb + (int64_t)h * p.dqs.sh);
+  const int tfirst = w.t0 + RPG * grp;
+  float4 qg[2][4];   // q / dO rows [t, t+1, t+2, t+3]: three rows of requests in flight ahead of the one being worked on
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    qg[0][k] = bld4(qrs, row_off(tfirst + k, T, p.qs.st, c4));
+    qg[1][k] = bld4(grs, row_off(tfirst + k, T, p.dos.st, c4));
+  }
+  float4 A[PM], Va[PM], accva[PM], acca[PM];
+#pragma unroll
+  for (int i = 0; i < PM; ++i) {
+    A[i] = i < P ? ld4(p.agents + (w.bh * P + i) * D + c4) : f4(0.f);
+    Va[i] = i < P ? ld4(p.vagent + (w.bh * P + i) * D + c4) : f4(0.f);
+    accva[i] = f4(0.f); acca[i] = f4(0.f);
+  }
+#pragma unroll 1
+  for (int j = 0; j < RPG; ++j) {
+    const float4 qv = qg[0][0], g = qg[1][0];
+    const bool ok = tfirst + j < T;
+    float sc[PM], dp[PM];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+      sc[i] = fold16(dot4(qv, A[i])) * p.scale;
+      dp[i] = fold16(dot4(g, Va[i]));
+      if (i < P) m = fmaxf(m, sc[i]);
+    }
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < PM; ++i) { sc[i] = i < P ? expf(sc[i] - m) : 0.f; l += sc[i]; }
+    const float il = ok ? 1.f / l : 0.f;   // (rows past the sequence: P2 = 0, dS2 = 0)
+    float dl = 0.f;
+#pragma unroll
+    for (int i = 0; i < PM; ++i) { sc[i] *= il; dl += sc[i] * dp[i]; }
+    float4 dq = f4(0.f);
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+      const float ds = sc[i] * (dp[i] - dl);
+      fma4(dq, ds * p.scale, A[i]);
+      fma4(accva[i], sc[i], g);
+      fma4(acca[i], ds, qv);
+    }
+    bst4(dqrs, row_off(tfirst + j, T, p.dqs.st, c4), dq);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      qg[k][0] = qg[k][1]; qg[k][1] = qg[k][2]; qg[k][2] = qg[k][3];
+      qg[k][3] = bld4(k == 0 ? qrs : grs, (j + 4 < RPG) ? row_off(tfirst + j + 4, T, k == 0 ? p.qs.st : p.dos.st, c4) : PAST);
+    }
+  }
+  // fold the 16 groups: 4 per wave by DPP, the 4 waves through LDS
+#pragma unroll
+  for (int i = 0; i < PM; ++i) {
+    if (i < P) {
+      const float4 a = fold_subs(accva[i]), b = fold_subs(acca[i]);
+      if (lane < 16) { st4(&red[((wave * 2 + 0) * PM + i) * D + c4], a); st4(&red[((wave * 2 + 1) * PM + i) * D + c4], b); }
+    }
+  }
+  __syncthreads();
+  const int64_t cell = w.bh * p.NC + w.ch;
+  for (int i = wave; i < P; i += 4) {
+    float sva = 0.f, sa = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) { sva += red[((ww * 2 + 0) * PM + i) * D + lane]; sa += red[((ww * 2 + 1) * PM + i) * D + lane]; }
+    p.pva[(cell * P + i) * D + lane] = sva;
+    p.pa2[(cell * P + i) * D + lane] = p.scale * sa;
+  }
+}
+
+template <int PM>
+__global__ __launch_bounds__(NT) void agent_s1_bwd_stream_kernel(BwdParams p) {
+  __shared__ __attribute__((aligned(16))) float red[4 * (PM + 10) * D];   // [wave][dA (PM) | dconv_w (9) | dconv_b][channel]
+  __shared__ __attribute__((aligned(16))) float wqs[9 * D];                // the convolution's taps [tap][channel]
+  __shared__ __attribute__((aligned(16))) float As[PM * D], dVas[PM * D];  // agents and dV_agent: 48 registers too many next
+                                                                           // to the 36 of the convolution's gradient
+  __shared__ float m1[PM], il1[PM], delta1[PM];
+  constexpr int RPG = CH / (NT / 16);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, grp = tid >> 4, c4 = (tid & 15) * 4;
+  const Where w = where(p.H, p.NC);
+  const int P = p.P, T = p.T, h = w.h;
+  const __amdgpu_buffer_rsrc_t krs = slab(p.k + (int64_t)w.b * p.ks.sb + (int64_t)h * p.ks.sh);
+  const __amdgpu_buffer_rsrc_t vrs = slab(p.v + (int64_t)w.b * p.vs.sb + (int64_t)h * p.vs.sh);
+  const __amdgpu_buffer_rsrc_t grs = slab(p.d_o + (int64_t)w.b * p.dos.sb);
+  const __amdgpu_buffer_rsrc_t dkrs = slab(p.dk + (int64_t)w.b * p.dks.sb + (int64_t)h * p.dks.sh);
+  const __amdgpu_buffer_rsrc_t dvrs = slab(p.dv + (int64_t)w.b * p.dvs.sb + (int64_t)h * p.dvs.sh);
+  const int tfirst = w.t0 + RPG * grp;
+  // dO rows of head h - (a - 1) at token t (zero padding): the window of the transposed depthwise convolution
+  auto ldg = [&](int a, int t) {
+    const int h2 = h - (a - 1);
+    return bld4(grs, (h2 >= 0 && h2 < p.H && t >= 0 && t < T) ? (unsigned)(((int64_t)h2 * p.dos.sh + (int64_t)t * p.dos.st + c4) * 4) : PAST);
+  };
+  float4 win[3][4], kv[2][3];   // dO window [head offset][t-1, t, t+1, t+2]; k / v rows [t, t+1, t+2]
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    win[a][0] = ldg(a, tfirst - 1); win[a][1] = ldg(a, tfirst); win[a][2] = ldg(a, tfirst + 1); win[a][3] = ldg(a, tfirst + 2);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { kv[0][k] = bld4(krs, row_off(tfirst + k, T, p.ks.st, c4)); kv[1][k] = bld4(vrs, row_off(tfirst + k, T, p.vs.st, c4)); }
+  if (tid < 9 * 16) {   // taps: wqs[j][c] = convw[c][j]
+    const int j = tid / 16, cc = (tid & 15) * 4;
+    st4(&wqs[j * D + cc], make_float4(p.convw[(cc + 0) * 9 + j], p.convw[(cc + 1) * 9 + j], p.convw[(cc + 2) * 9 + j], p.convw[(cc + 3) * 9 + j]));
+  }
+  if (tid < P) {
+    const int64_t row = w.bh * P + tid;
+    m1[tid] = p.stats1[row * 2]; il1[tid] = 1.f / p.stats1[row * 2 + 1]; delta1[tid] = p.delta1[row];
+  }
+  for (int i = wave; i < P; i += 4) {
+    As[i * D + lane] = p.agents[(w.bh * P + i) * D + lane];
+    dVas[i * D + lane] = p.dva[(w.bh * P + i) * D + lane];
+  }
+  float4 acca[PM], dw9[9], dbs = f4(0.f);
+#pragma unroll
+  for (int i = 0; i < PM; ++i) acca[i] = f4(0.f);
+#pragma unroll
+  for (int j = 0; j < 9; ++j) dw9[j] = f4(0.f);
+  __syncthreads();
+#pragma unroll 1
+  for (int j = 0; j < RPG; ++j) {
+    const int t = tfirst + j;
+    const float4 kr = kv[0][0], vr = kv[1][0];
+    const bool ok = t < T;
+    float4 dk = f4(0.f), dvv = f4(0.f);
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+      for (int bb = 0; bb < 3; ++bb) {
+        mad4(dvv, ld4(&wqs[(a * 3 + bb) * D + c4]), win[a][2 - bb]);   // dv[h, t] += w[a][b] dO[h - (a-1), t - (b-1)]
+        mad4(dw9[a * 3 + bb], vr, win[a][2 - bb]);                      // (v is zero past the sequence)
+      }
+    dbs.x += win[1][1].x; dbs.y += win[1][1].y; dbs.z += win[1][1].z; dbs.w += win[1][1].w;   // dO[h, t]
+#pragma unroll
+    for (int i = 0; i < PM; ++i) {
+      if (i < P) {
+        const float4 Ai = ld4(&As[i * D + c4]), dVi = ld4(&dVas[i * D + c4]);
+        const float s = fold16(dot4(kr, Ai)), dp = fold16(dot4(vr, dVi));
+        const float pr = ok ? expf(s * p.scale - m1[i]) * il1[i] : 0.f;
+        const float ds = pr * (dp - delta1[i]);
+        fma4(dk, ds * p.scale, Ai);
+        fma4(dvv, pr, dVi);
+        fma4(acca[i], ds, kr);
+      }
+    }
+    bst4(dkrs, row_off(t, T, p.dks.st, c4), dk);
+    bst4(dvrs, row_off(t, T, p.dvs.st, c4), dvv);
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      win[a][0] = win[a][1]; win[a][1] = win[a][2]; win[a][2] = win[a][3];
+      win[a][3] = ldg(a, (j + 3 <= RPG) ? t + 3 : -1);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      kv[k][0] = kv[k][1]; kv[k][1] = kv[k][2];
+      kv[k][2] = bld4(k == 0 ? krs : vrs, (j + 3 < RPG) ? row_off(t + 3, T, k == 0 ? p.ks.st : p.vs.st, c4) : PAST);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PM; ++i) {
+    if (i < P) {
+      const float4 a = fold_subs(acca[i]);
+      if (lane < 16) st4(&red[(wave * (PM + 10) + i) * D + c4], a);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 9; ++j) {
+    const float4 a = fold_subs(dw9[j]);
+    if (lane < 16) st4(&red[(wave * (PM + 10) + PM + j) * D + c4], a);
+  }
+  {
+    const float4 a = fold_subs(dbs);
+    if (lane < 16) st4(&red[(wave * (PM + 10) + PM + 9) * D + c4], a);
+  }
+  __syncthreads();
+  const int64_t cell = w.bh * p.NC + w.ch;
+  auto fold = [&](int slot) {
+    float x = 0.f;
+#pragma unroll
+    for (int ww = 0; ww < 4; ++ww) x += red[(ww * (PM + 10) + slot) * D + lane];
+    return x;
+  };
+  for (int i = wave; i < P; i += 4) p.pa1[(cell * P + i) * D + lane] = p.scale * fold(i);
+  for (int j = wave; j < 10; j += 4) {
+    if (j < 9) p.dconvw_part[(cell * 9 + j) * D + lane] = fold(PM + j);
+    else p.dconvb_part[cell * D + lane] = fold(PM + 9);
+  }
+}
+
 // backward 3: dq[b,h,t,:] += sum over the bins i containing t of dA[b,h,i,:] / len(bin i), with
 // dA = dA(stage 2) + the chunk partials of dA(stage 1) folded in chunk order.  One workgroup per
 // (b, h, 64-token block): dA / len of the bins that meet the block is rebuilt in LDS first.
@@ -887,9 +1110,24 @@ extern "C" int amk_agent_attn_bwd(const float* q, const float* k, const float* v
   const int64_t pblk = (int64_t)B * H * ((T + PB - 1) / PB);
   AMK_CHECK_SUPPORTED(pblk < (1ll << 31), "amk_agent_attn_bwd: B*h*T exceeds the grid limit");
   hipStream_t st = static_cast<hipStream_t>(stream);
-  AMK_AGENT_LAUNCH(agent_s2_bwd_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
+  static int stream_mode = -1;   // AMK_AGENT_STREAM=0: the LDS-staged chunk kernels also for P <= 8
+  if (stream_mode < 0) {
+    const char* e = getenv("AMK_AGENT_STREAM");
+    stream_mode = e ? atoi(e) : 1;
+  }
+  const bool streaming = stream_mode && P <= 8;
+#define AMK_AGENT_STREAM_LAUNCH(KERNEL)                                                                \
+  do {                                                                                                  \
+    if (P <= 4) hipLaunchKernelGGL(KERNEL<4>, dim3((unsigned)cells), dim3(NT), 0, st, p);              \
+    else if (P <= 6) hipLaunchKernelGGL(KERNEL<6>, dim3((unsigned)cells), dim3(NT), 0, st, p);         \
+    else hipLaunchKernelGGL(KERNEL<8>, dim3((unsigned)cells), dim3(NT), 0, st, p);                     \
+  } while (0)
+  if (streaming) AMK_AGENT_STREAM_LAUNCH(agent_s2_bwd_stream_kernel);
+  else AMK_AGENT_LAUNCH(agent_s2_bwd_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
   hipLaunchKernelGGL(agent_mid_kernel, dim3((unsigned)(B * H)), dim3(256), 0, st, p);
-  AMK_AGENT_LAUNCH(agent_s1_bwd_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
+  if (streaming) AMK_AGENT_STREAM_LAUNCH(agent_s1_bwd_stream_kernel);
+  else AMK_AGENT_LAUNCH(agent_s1_bwd_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
+#undef AMK_AGENT_STREAM_LAUNCH
   hipLaunchKernelGGL(agent_pool_bwd_kernel, dim3((unsigned)pblk), dim3(NT), 0, st, p);
   AMK_CHECK_LAUNCH("amk_agent_attn_bwd");
   return AMK_OK;
