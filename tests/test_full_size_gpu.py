@@ -191,3 +191,46 @@ def test_vitvqgan_config2_full_size_train_step(device):
         assert torch.equal(logs[k], logs2[k]), k
     for (n, p), q in zip(model.named_parameters(), model2.parameters()):
         assert float((p.detach() - q.detach()).abs().max()) <= 1e-5 * max(1.0, float(p.detach().abs().max())) + 2.1e-4, n  # (+ 2 lr: an Adam sign flip)
+
+
+def test_bf16_gemms_at_the_configs2_layer_shape(device):
+    """The mixed-precision GEMMs (csrc/gemm_bf16.hip) at the full configs[2] layer shape (batch 32: M = 32 768 rows, the FFN's
+    256 -> 2 x 1368 -> 256): size-independent properties and a float64 check of sampled rows / columns.
+      * w12 + SwiGLU: the gate equals silu(a) * b of the (a | b) the same launch wrote (bf16-exactly up to one rounding);
+      * dY W3 + gate backward equals the two-launch form bit for bit where the products agree;
+      * dW / db: linear in dY (dW(2 dY) = 2 dW(dY) exactly), reproducible, and right on sampled entries."""
+    import torch.nn.functional as F
+
+    from amk import dense
+
+    M, Dm, H = 32768, 256, 1368
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(M, Dm, generator=g).bfloat16().to(device)
+    w12 = (torch.randn(2 * H, Dm, generator=g) * Dm ** -0.5).bfloat16().to(device)
+    b12 = (torch.randn(2 * H, generator=g) * 0.1).to(device)
+    w3 = (torch.randn(Dm, H, generator=g) * H ** -0.5).bfloat16().to(device)
+    dy = torch.randn(M, Dm, generator=g).bfloat16().to(device)
+    gate, ab = dense.gemm_nt_swiglu_bf16(x, w12, b12)
+    assert gate.shape == (M, H) and ab.shape == (M, 2 * H)
+    assert torch.isfinite(gate.float()).all() and torch.isfinite(ab.float()).all()
+    rows = torch.tensor([0, 1, 127, 128, 4095, 16384, 32767], device=device)
+    ref_ab = x[rows].double() @ w12.double().t() + b12.double()
+    assert float((ab[rows].double() - ref_ab).abs().max()) <= 2 ** -7 * float(ref_ab.abs().max())
+    ref_g = F.silu(ref_ab[:, :H]) * ref_ab[:, H:]
+    assert float((gate[rows].double() - ref_g).abs().max()) <= 2 ** -7 * float(ref_g.abs().max())
+    gate_only, none = dense.gemm_nt_swiglu_bf16(x, w12, b12, keep_ab=False)
+    assert none is None and torch.equal(gate_only, gate)
+    dab = dense.gemm_nn_swiglu_bwd_bf16(dy, w3, ab)
+    assert dab.shape == (M, 2 * H) and torch.isfinite(dab.float()).all()
+    abr = ab[rows].double().requires_grad_(True)
+    (ref_dab,) = torch.autograd.grad(F.silu(abr[:, :H]) * abr[:, H:], abr, dy[rows].double() @ w3.double())
+    assert float((dab[rows].double() - ref_dab).abs().max()) <= 2e-2 * float(ref_dab.abs().max())
+    dw, db = dense.gemm_tn_bf16(dab, x, want_bias=True)
+    dw2, db2 = dense.gemm_tn_bf16((2.0 * dab.float()).bfloat16(), x, want_bias=True)   # (doubling is exact in bf16)
+    assert torch.equal(dw2, 2.0 * dw) and torch.equal(db2, 2.0 * db)
+    again = dense.gemm_tn_bf16(dab, x, want_bias=True)
+    assert torch.equal(again[0], dw) and torch.equal(again[1], db)
+    cols = torch.tensor([0, 1, 1367, 1368, 2735], device=device)
+    ref_dw = dab[:, cols].double().t() @ x.double()
+    assert float((dw[cols].double() - ref_dw).abs().max()) <= 2e-5 * float(ref_dw.abs().max())
+    assert float((db[cols].double() - dab[:, cols].double().sum(0)).abs().max()) <= 2e-5 * float(db.abs().max())
