@@ -1208,7 +1208,9 @@ def _w16(t):
     if t is None:
         return None
     shadow = getattr(t, "_amk_bf16", None)
-    return shadow if shadow is not None else t.to(torch.bfloat16)
+    if shadow is not None and t._version == t._amk_bf16_version:
+        return shadow
+    return t.to(torch.bfloat16)   # no copy kept, or the parameter was written in place since (load_state_dict, init): cast
 
 
 class _LinearMixed(torch.autograd.Function):

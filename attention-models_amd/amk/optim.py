@@ -85,18 +85,23 @@ class FlatAdam:
             f16 = fp.to(torch.bfloat16)
             for p, off in zip(b.params, b.offsets):
                 p._amk_bf16 = f16[off:off + p.numel()].view_as(p)
+                p._amk_bf16_version = p._version   # (the update kernel writes behind torch's back: the version stays)
             self.flat_p16.append(f16)
 
     def disable_shadow(self):
         for p in self.params:
             if hasattr(p, "_amk_bf16"):
                 del p._amk_bf16
+                del p._amk_bf16_version
         self.flat_p16 = []
 
     def refresh_shadow(self):
         """Re-derive the bf16 copies from the fp32 parameters (after anything but ``step`` wrote them)."""
         for fp, f16 in zip(self.flat_p, self.flat_p16):
             f16.copy_(fp)
+        if self.flat_p16:
+            for p in self.params:
+                p._amk_bf16_version = p._version
 
     @property
     def lr(self):

@@ -282,4 +282,6 @@ class VQGANTrainStep:
         self.global_step = int(ckpt["step"])
         self.model.load_state_dict(ckpt["state_dict"])
         self.g_red.broadcast_parameters()
+        if self.fused_optimizer:
+            self.g_optim.refresh_shadow()   # (the bf16 copies the mixed-precision GEMMs read: written behind the optimizer's back)
         return ckpt.get("config")

@@ -94,5 +94,9 @@ def test_flat_adam_bf16_shadow(device):
     assert ops._w16(net.b.weight) is net.b.weight._amk_bf16
     with torch.no_grad():
         net.b.weight.mul_(2.0)
+    # written behind the optimizer's back: the stale copy is not used (the in-place write bumped the tensor's version)
+    assert ops._w16(net.b.weight) is not net.b.weight._amk_bf16
+    assert torch.equal(ops._w16(net.b.weight), net.b.weight.detach().to(torch.bfloat16))
     opt.refresh_shadow()
+    assert ops._w16(net.b.weight) is net.b.weight._amk_bf16
     assert torch.equal(net.b.weight._amk_bf16, net.b.weight.detach().to(torch.bfloat16))
