@@ -148,18 +148,39 @@ def gemm_nn(a, w, *, a2=None, w2=None, swiglu_ab=None):
     return c
 
 
-def gemm_tn(y, x, *, y2=None, ln=None, want_bias=False):
+def _out(t, shape, what):
+    """A caller-provided result buffer (a gradient view of amk.dp.GradReducer): fp32, contiguous, 16-byte aligned."""
+    if t is None:
+        return None
+    if (not t.is_cuda or t.dtype != torch.float32 or tuple(t.shape) != tuple(shape) or not t.is_contiguous()
+            or t.data_ptr() % 16):
+        raise RuntimeError(f"{what}: an fp32 contiguous 16-byte aligned HIP tensor of shape {tuple(shape)} is required")
+    return t
+
+
+def gemm_tn(y, x, *, y2=None, ln=None, want_bias=False, out=None, out2=None, bias_out=None):
     """y^T @ x' (x' = x or LayerNorm(x)): the weight gradient dY^T X of F.linear; with y2 a second gradient against the
-    same x (y.shape[1] a multiple of 128).  Returns (dw, dw2 or None, colsum(y | y2) or None)."""
+    same x (y.shape[1] a multiple of 128).  Returns (dw, dw2 or None, colsum(y | y2) or None).  out / out2 / bias_out:
+    write the results there (OVERWRITING) instead of into fresh tensors."""
     y, x, y2 = _mat(y, "y"), _mat(x, "x"), _mat(y2, "y2")
     M, N1 = y.shape
     K = x.shape[1]
     N2 = y2.shape[1] if y2 is not None else 0
     if x.shape[0] != M or (y2 is not None and y2.shape[0] != M):
         raise RuntimeError(f"gemm_tn: y {tuple(y.shape)} against x {tuple(x.shape)}")
-    dw = torch.empty((N1, K), device=y.device, dtype=torch.float32)
-    dw2 = torch.empty((N2, K), device=y.device, dtype=torch.float32) if y2 is not None else None
-    db = torch.empty((N1 + N2,), device=y.device, dtype=torch.float32) if want_bias else None
+    dw = _out(out, (N1, K), "gemm_tn out")
+    if dw is None:
+        dw = torch.empty((N1, K), device=y.device, dtype=torch.float32)
+    dw2 = None
+    if y2 is not None:
+        dw2 = _out(out2, (N2, K), "gemm_tn out2")
+        if dw2 is None:
+            dw2 = torch.empty((N2, K), device=y.device, dtype=torch.float32)
+    db = None
+    if want_bias:
+        db = _out(bias_out, (N1 + N2,), "gemm_tn bias_out")
+        if db is None:
+            db = torch.empty((N1 + N2,), device=y.device, dtype=torch.float32)
     d = GemmDesc(op=GEMM_TN, epilogue=EPI_BIAS, m=M, n=N1 + N2, k=K, split=N1 if y2 is not None else 0)
     d.a, d.lda, d.w, d.ldw, d.c, d.ldc, d.dbias = _p(y), y.stride(0), _p(x), x.stride(0), _p(dw), K, _p(db)
     if y2 is not None:
@@ -187,9 +208,9 @@ def supported_bf16(N, K):
     return N > 0 and K > 0 and N % 8 == 0 and K % 8 == 0
 
 
-def gemm_tn_bf16(y, x, want_bias=False):
+def gemm_tn_bf16(y, x, want_bias=False, out=None, bias_out=None):
     """(dW (N, K) f32, db (N,) f32 or None) = (y^T x, column sums of y) for bf16 y (M, N), x (M, K): the weight and bias
-    gradient of nn.Linear under autocast (csrc/gemm_bf16.hip)."""
+    gradient of nn.Linear under autocast (csrc/gemm_bf16.hip).  out / bias_out: write there (OVERWRITING)."""
     y, x = _mat16(y, "y"), _mat16(x, "x")
     M, N = y.shape
     K = x.shape[1]
@@ -198,8 +219,14 @@ def gemm_tn_bf16(y, x, want_bias=False):
     if not supported_bf16(N, K):
         raise RuntimeError(f"gemm_tn_bf16: N and K must be multiples of 8, got {N}, {K}")
     L = _lib.load()
-    dw = torch.empty(N, K, device=y.device, dtype=torch.float32)
-    db = torch.empty(N, device=y.device, dtype=torch.float32) if want_bias else None
+    dw = _out(out, (N, K), "gemm_tn_bf16 out")
+    if dw is None:
+        dw = torch.empty(N, K, device=y.device, dtype=torch.float32)
+    db = None
+    if want_bias:
+        db = _out(bias_out, (N,), "gemm_tn_bf16 bias_out")
+        if db is None:
+            db = torch.empty(N, device=y.device, dtype=torch.float32)
     nbytes = L.amk_gemm_tn_bf16_ws_bytes(M, N, K)
     ws = torch.empty(nbytes // 4, device=y.device, dtype=torch.float32) if nbytes else None
     rc = L.amk_gemm_tn_bf16(_p(y), y.stride(0), _p(x), x.stride(0), _p(dw), K, _p(db), M, N, K, _p(ws), nbytes, _stream())

@@ -32,6 +32,9 @@ Design (MI355X: 7 xGMI links x ~153 GB/s per GPU, ring collectives are per-link 
     (``accelerator.accumulate`` / ``no_sync`` semantics).
 Works unchanged on CPU tensors with the gloo backend (used by the world_size-2 tests).
 """
+import os
+import weakref
+
 import torch
 import torch.distributed as dist
 
@@ -39,17 +42,19 @@ ALIGN = 256  # elements: a parameter's slice of its bucket starts on a 1-KiB bou
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "views", "offsets", "pending", "ready", "launched", "work", "fired", "static_unused")
+    __slots__ = ("flat", "params", "views", "offsets", "pending", "ready", "launched", "work", "fired", "static_unused", "direct")
 
     def __init__(self, flat, params, views, offsets):
         self.flat, self.params, self.views, self.offsets = flat, params, views, offsets
         self.pending, self.ready, self.launched, self.work = len(params), False, False, None
         self.fired = [False] * len(params)
         self.static_unused = None  # per parameter: never receives a gradient on any rank (recorded by the first sync step)
+        self.direct = [False] * len(params)  # per parameter: this step's gradient was written into its view by a kernel
 
 
 class GradReducer:
-    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, communicate_when_alone=False, static_unused=True):
+    def __init__(self, params, bucket_bytes=32 << 20, process_group=None, communicate_when_alone=False, static_unused=True,
+                 direct_grads=False):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradReducer: no trainable parameters")
@@ -64,6 +69,11 @@ class GradReducer:
         self.side = torch.cuda.Stream(device=dev) if self.on_gpu else None
         self.sync_step = True
         self.static_unused = bool(static_unused)
+        # direct_grads: the weight-gradient kernels of amk.ops write a parameter's FIRST gradient of a step straight into its
+        # (zeroed) bucket view -- claim() / wrote() below -- instead of returning a tensor for autograd to add to it: one
+        # element-wise launch less per parameter and step.  For models in which a parameter meets one custom backward per
+        # step (no weight sharing between such layers); a second contribution after the bucket left raises.
+        self.direct_grads = bool(direct_grads) and os.environ.get("AMK_DIRECT_GRADS", "1") == "1"
         self.buckets = []
         self._bucket_of = {}
         self._next = 0  # index of the next bucket to send
@@ -79,6 +89,9 @@ class GradReducer:
         if cur:
             self._close(cur, dev)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+        me = weakref.ref(self)
+        for p in self.params:
+            p._amk_reducer = me
 
     # ------------------------------------------------------------------ construction
     def _close(self, params, dev):
@@ -113,6 +126,7 @@ class GradReducer:
         self.launch_order = []
         for b in self.buckets:
             b.pending, b.ready, b.launched, b.work = len(b.params), False, False, None
+            b.direct = [False] * len(b.params)
             if b.static_unused is not None:
                 b.pending -= sum(b.static_unused)  # not waited for
                 b.ready = b.pending == 0           # only such parameters: its zeros leave with the first bucket that completes
@@ -134,12 +148,41 @@ class GradReducer:
             for p, v in zip(b.params, b.views):
                 p.grad = v
 
+    def claim(self, p):
+        """The bucket view to write p's gradient into, if this is the first gradient p receives since the bucket was zeroed
+        (else None: the caller returns a tensor and autograd accumulates).  The caller must call wrote(p) after launching
+        the kernel that fills the view."""
+        if not self.direct_grads:
+            return None
+        ent = self._bucket_of.get(p)
+        if ent is None:
+            return None
+        b, i = ent
+        if b.fired[i] or b.launched or p.grad is not b.views[i]:
+            return None
+        return b.views[i]
+
+    def wrote(self, p):
+        """p's gradient now sits in its bucket view (written on the current stream): what the post-accumulate hook does."""
+        b, i = self._bucket_of[p]
+        b.direct[i] = True
+        self._count(b, i)
+
     def _on_grad(self, p):
         b, i = self._bucket_of[p]
+        if b.direct[i]:
+            # a further contribution through autograd after a direct write: p.grad (the view) already holds the sum
+            if b.launched and not self.alone:
+                raise RuntimeError("GradReducer(direct_grads=True): a parameter received a second gradient after its bucket "
+                                   "was sent (a weight shared between layers?); construct with direct_grads=False")
+            return
         view = b.views[i]
         if p.grad.data_ptr() != view.data_ptr():
             view.copy_(p.grad)  # autograd (create_graph) or an optimizer replaced .grad: fold it back
             p.grad = view
+        self._count(b, i)
+
+    def _count(self, b, i):
         b.fired[i] = True
         if b.static_unused is not None and b.static_unused[i]:
             if b.launched and not self.alone:

@@ -1107,6 +1107,17 @@ def _nn_plain(dy2, weight):
     return dy2.mm(weight)
 
 
+def _claim(p):
+    """(reducer, view): the gradient view of amk.dp.GradReducer(direct_grads=True) to write parameter p's gradient into,
+    when this is its first gradient of the step -- else (None, None) and the caller returns a tensor for autograd."""
+    ref = getattr(p, "_amk_reducer", None) if p is not None else None
+    red = ref() if ref is not None else None
+    if red is None:
+        return None, None
+    view = red.claim(p)
+    return (red, view) if view is not None else (None, None)
+
+
 class _DenseLinear(torch.autograd.Function):
     """F.linear on amk_gemm_f32: forward NT (+ bias), dX = dY W, dW = dY^T X with db = colsum(dY) in the same launch."""
 
@@ -1118,6 +1129,7 @@ class _DenseLinear(torch.autograd.Function):
         ctx.save_for_backward(x2, weight)
         ctx.x_shape = x.shape
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         if DENSE_MODE == "auto" and weight.shape[0] < 512:
             # outputs of one or two column tiles (W_o, w3, patch / quant layers: one tile per workgroup, nothing for the
             # persistent walk to overlap): the library's kernel is 5-10 % faster there (tools/kbench_dense.py)
@@ -1134,8 +1146,31 @@ class _DenseLinear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _nn_plain(dy2, weight).view(ctx.x_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            dw, _, db = dense.gemm_tn(dy2, x2, want_bias=ctx.has_bias and ctx.needs_input_grad[2])
+            want_b = ctx.has_bias and ctx.needs_input_grad[2]
+            (wr, wv), (br, bv) = _claim(ctx.params[0]), (_claim(ctx.params[1]) if want_b else (None, None))
+            dw, _, db = dense.gemm_tn(dy2, x2, want_bias=want_b, out=wv, bias_out=bv)
+            if wv is not None:
+                wr.wrote(ctx.params[0])
+                dw = None
+            if bv is not None:
+                br.wrote(ctx.params[1])
+                db = None
         return dx, dw, db
+
+
+def _tn_into(tn, y, x, weight, bias):
+    """(dW, db) of a Linear layer by `tn` (dense.gemm_tn / gemm_tn_bf16), written straight into the reducer's gradient views
+    where they can be claimed (those come back as None: nothing for autograd to add)."""
+    (wr, wv), (br, bv) = _claim(weight), _claim(bias)
+    res = tn(y, x, want_bias=bias is not None, out=wv, bias_out=bv)
+    dw, db = res[0], res[-1]
+    if wv is not None:
+        wr.wrote(weight)
+        dw = None
+    if bv is not None:
+        br.wrote(bias)
+        db = None
+    return dw, db
 
 
 class _DenseLinear2(torch.autograd.Function):
@@ -1149,6 +1184,7 @@ class _DenseLinear2(torch.autograd.Function):
         x2 = x.reshape(-1, x.shape[-1])
         ctx.save_for_backward(x2, wa, wb)
         ctx.x_shape = x.shape
+        ctx.params = (wa, wb)
         a, b = dense.gemm_nt(x2, wa, None, w2=wb)
         return a.view(*x.shape[:-1], wa.shape[0]), b.view(*x.shape[:-1], wb.shape[0])
 
@@ -1162,7 +1198,14 @@ class _DenseLinear2(torch.autograd.Function):
         dx = dense.gemm_nn(da2, wa, a2=db2, w2=wb).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
         dwa = dwb = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dwa, dwb, _ = dense.gemm_tn(da2, x2, y2=db2)
+            (ar, av), (br, bv) = _claim(ctx.params[0]), _claim(ctx.params[1])
+            dwa, dwb, _ = dense.gemm_tn(da2, x2, y2=db2, out=av, out2=bv)
+            if av is not None:
+                ar.wrote(ctx.params[0])
+                dwa = None
+            if bv is not None:
+                br.wrote(ctx.params[1])
+                dwb = None
         return dx, dwa, dwb
 
 
@@ -1184,6 +1227,7 @@ class _SwiGLUFFN(torch.autograd.Function):
             ctx.save_for_backward(x2, w12, w3, ab, gate)
         ctx.x_shape = x.shape
         ctx.has_bias = (b12 is not None, b3 is not None)
+        ctx.params = (w12, b12, w3, b3)
         return out.view(*x.shape[:-1], w3.shape[0])
 
     @staticmethod
@@ -1193,9 +1237,9 @@ class _SwiGLUFFN(torch.autograd.Function):
         x2, w12, w3, ab, gate = ctx.saved_tensors
         d2 = dout.reshape(-1, dout.shape[-1])
         d_ab = dense.gemm_nn(d2, w3, swiglu_ab=ab)
-        dw3, _, db3 = dense.gemm_tn(d2, gate, want_bias=ctx.has_bias[1])
+        dw3, db3 = _tn_into(dense.gemm_tn, d2, gate, ctx.params[2], ctx.params[3] if ctx.has_bias[1] else None)
         dx = _nn_plain(d_ab, w12).view(ctx.x_shape) if ctx.needs_input_grad[0] else None
-        dw12, _, db12 = dense.gemm_tn(d_ab, x2, want_bias=ctx.has_bias[0])
+        dw12, db12 = _tn_into(dense.gemm_tn, d_ab, x2, ctx.params[0], ctx.params[1] if ctx.has_bias[0] else None)
         return dx, dw12, db12, dw3, db3
 
 
@@ -1223,6 +1267,7 @@ class _LinearMixed(torch.autograd.Function):
         x16, w16 = x.to(torch.bfloat16), _w16(weight)
         ctx.save_for_backward(x16, w16)
         ctx.has_bias, ctx.x_dtype = bias is not None, x.dtype
+        ctx.params = (weight, bias)
         return torch.nn.functional.linear(x16, w16, _w16(bias))
 
     @staticmethod
@@ -1232,7 +1277,7 @@ class _LinearMixed(torch.autograd.Function):
         x16, w16 = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
         dx = dy2.mm(w16).view(x16.shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
-        dw, db = dense.gemm_tn_bf16(dy2, x16.reshape(-1, x16.shape[-1]), want_bias=ctx.has_bias)
+        dw, db = _tn_into(dense.gemm_tn_bf16, dy2, x16.reshape(-1, x16.shape[-1]), ctx.params[0], ctx.params[1])
         return dx, dw, db
 
 
@@ -1279,6 +1324,7 @@ class _SwiGLUFFNMixed(torch.autograd.Function):
         y = torch.nn.functional.linear(g, w3h, _w16(b3))
         ctx.save_for_backward(x16, ab, g, w12h, w3h)
         ctx.x_shape, ctx.x_dtype, ctx.bias = x.shape, x.dtype, (b12 is not None, b3 is not None)
+        ctx.params = (w12, b12, w3, b3)
         return y.view(*x.shape[:-1], w3.shape[0])
 
     @staticmethod
@@ -1287,9 +1333,9 @@ class _SwiGLUFFNMixed(torch.autograd.Function):
 
         x16, ab, g, w12h, w3h = ctx.saved_tensors
         dy2 = dy.reshape(-1, dy.shape[-1])
-        dw3, db3 = dense.gemm_tn_bf16(dy2, g, want_bias=ctx.bias[1])
+        dw3, db3 = _tn_into(dense.gemm_tn_bf16, dy2, g, ctx.params[2], ctx.params[3])
         dab = dense.gemm_nn_swiglu_bwd_bf16(dy2, w3h, ab)   # dY W3 with the gate's backward in its epilogue
-        dw12, db12 = dense.gemm_tn_bf16(dab, x16, want_bias=ctx.bias[0])
+        dw12, db12 = _tn_into(dense.gemm_tn_bf16, dab, x16, ctx.params[0], ctx.params[1])
         dx = dab.mm(w12h).view(ctx.x_shape).to(ctx.x_dtype) if ctx.needs_input_grad[0] else None
         return dx, dw12, db12, dw3, db3
 

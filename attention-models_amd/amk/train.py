@@ -54,7 +54,9 @@ class VQGANTrainStep:
         self.max_grad_norm, self.gp_lambda = max_grad_norm, gp_lambda
         self.base_lr, self.warmup_steps, self.decay_steps = lr, warmup_steps, decay_steps
         fused = next(model.parameters()).is_cuda
-        self.g_red = GradReducer(model.parameters(), bucket_bytes)
+        # direct_grads: the Linear layers' weight-gradient kernels write straight into the generator's gradient buckets (no
+        # weight is shared between two such layers in ViTVQGAN); the discriminator's convolutions go through autograd
+        self.g_red = GradReducer(model.parameters(), bucket_bytes, direct_grads=fused)
         self.d_red = GradReducer(discr.parameters(), bucket_bytes)
         # fused_optimizer (default on the GPU): amk.optim.FlatAdam -- clip + Adam + zeroing in two passes over the
         # reducer's flat buckets (csrc/optim.hip) instead of clip_grad_norm_ + Adam.step + zero_grad.

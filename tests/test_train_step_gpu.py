@@ -72,3 +72,33 @@ def test_one_train_step_matches_the_oracle_step(device, fused_optimizer):
         n_bad += int((d > 0.05 * lr).sum())
         n_all += d.numel()
     assert n_all > 100000 and n_bad <= 1e-3 * n_all, (n_bad, n_all)
+
+
+def test_direct_gradient_writes_match_accumulated_gradients(device):
+    """GradReducer(direct_grads=True): the Linear layers' weight / bias gradients written straight into the bucket views
+    equal the gradients autograd accumulates (same kernels, one element-wise add less), also over two accumulated
+    micro-steps (the second contribution goes through autograd), and every parameter is marked as fired."""
+    import copy
+
+    from amk.dp import GradReducer
+    from amk.models import ViTVQGAN
+
+    vit = dict(dim=128, img_size=32, patch_size=8, n_heads=2, d_head=64, depth=1, mlp_dim=768, dropout=0.0)
+    torch.manual_seed(0)
+    a = ViTVQGAN(vit, dict(codebook_size=64, codebook_dim=32)).to(device)
+    b = copy.deepcopy(a)
+    ra, rb = GradReducer(a.parameters(), direct_grads=True), GradReducer(b.parameters(), direct_grads=False)
+    assert ra.direct_grads and not rb.direct_grads
+    imgs = [torch.rand(4, 3, 32, 32, device=device) for _ in range(2)]
+    for micro, img in enumerate(imgs):
+        for net, red in ((a, ra), (b, rb)):
+            red.begin(sync=micro == 1)
+            rec, _ = net(img)
+            ((rec - img) ** 2).mean().backward()
+            red.finish(detach_unused=False)
+        wrote = sum(sum(bk.direct) for bk in ra.buckets)
+        assert (wrote > 0) == (micro == 0)      # first gradients are written in place, later ones accumulate through autograd
+    for (n, p), q in zip(a.named_parameters(), b.parameters()):
+        assert p.grad is not None and q.grad is not None, n
+        assert float((p.grad - q.grad).abs().max()) <= 1e-6 * max(1.0, float(q.grad.abs().max())), n
+    assert [f for bk in ra.buckets for f in bk.fired] == [f for bk in rb.buckets for f in bk.fired]
