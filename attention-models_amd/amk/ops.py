@@ -823,15 +823,41 @@ def _ln_supported(D):
     return 0 < D <= 4096 and D % 4 == 0
 
 
-def _ln_backward(dy, h, dh_in, weight, mean, rstd):
+def _ln_param_grads(part, params):
+    """(d gamma, d beta) from the kernel's (rows, 2, D) partial sums; summed straight into the reducer's gradient views
+    where they can be claimed (amk.dp.GradReducer(direct_grads=True): those come back as None)."""
+    weight, bias = params if params is not None else (None, None)
+    (wr, wv), (br, bv) = _claim_late(weight), _claim_late(bias)
+    if wv is None and bv is None:
+        dgb = part.sum(0)
+        return dgb[0], dgb[1]
+    dw = db = None
+    if wv is not None:
+        torch.sum(part[:, 0], dim=0, out=wv)
+        wr.wrote(weight)
+    else:
+        dw = part[:, 0].sum(0)
+    if bv is not None:
+        torch.sum(part[:, 1], dim=0, out=bv)
+        br.wrote(bias)
+    else:
+        db = part[:, 1].sum(0)
+    return dw, db
+
+
+def _claim_late(p):
+    return _claim(p)   # (_claim is defined with the Linear layers below)
+
+
+def _ln_backward(dy, h, dh_in, weight, mean, rstd, params=None):
     M, D = h.shape
     L = _lib.load()
     dh = torch.empty_like(h)
     part = torch.empty((L.amk_rowsum_num_partials(M), 2, D), device=h.device, dtype=torch.float32)
     _lib.check(L.amk_add_layernorm_bwd(_ptr(dy), _ptr(h), _ptr(dh_in), _ptr(weight), _ptr(mean), _ptr(rstd),
                                        M, D, _ptr(dh), _ptr(part), _stream()), "amk_add_layernorm_bwd")
-    dgb = part.sum(0)
-    return dh, dgb[0], dgb[1]
+    dw, db = _ln_param_grads(part, params)
+    return dh, dw, db
 
 
 class _LayerNorm(torch.autograd.Function):
@@ -851,13 +877,14 @@ class _LayerNorm(torch.autograd.Function):
                                            _ptr(mean), _ptr(rstd), _stream()), "amk_add_layernorm_fwd")
         ctx.save_for_backward(x2, w, mean, rstd)
         ctx.shape = x.shape
+        ctx.params = (weight, bias)
         return y.view(x.shape)
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, dy):
         x2, w, mean, rstd = ctx.saved_tensors
-        dx, dw, db = _ln_backward(dy.contiguous().view(x2.shape), x2, None, w, mean, rstd)
+        dx, dw, db = _ln_backward(dy.contiguous().view(x2.shape), x2, None, w, mean, rstd, ctx.params)
         return dx.view(ctx.shape), dw, db, None
 
 
@@ -882,6 +909,7 @@ class _AddLayerNorm(torch.autograd.Function):
                                            _ptr(mean), _ptr(rstd), _stream()), "amk_add_layernorm_fwd")
         ctx.save_for_backward(h, w, mean, rstd)
         ctx.shape = x.shape
+        ctx.params = (weight, bias)
         ctx.set_materialize_grads(False)
         return h.view(x.shape), y.view(x.shape)
 
@@ -894,7 +922,7 @@ class _AddLayerNorm(torch.autograd.Function):
                 return None, None, None, None, None
             return dh_in, dh_in, None, None, None
         dh2 = dh_in.contiguous().view(h.shape) if dh_in is not None else None
-        dh, dw, db = _ln_backward(dy.contiguous().view(h.shape), h, dh2, w, mean, rstd)
+        dh, dw, db = _ln_backward(dy.contiguous().view(h.shape), h, dh2, w, mean, rstd, ctx.params)
         dh = dh.view(ctx.shape)
         return dh, dh, dw, db, None
 
@@ -926,6 +954,7 @@ class _AddLayerNormMixed(torch.autograd.Function):
         hs = h if need_h else x2
         ctx.save_for_backward(hs, w, mean, rstd)
         ctx.cfg = (x.shape, xb, res is not None)
+        ctx.params = (weight, bias)
         ctx.set_materialize_grads(False)
         return hs.view(x.shape), y.view(x.shape)
 
@@ -948,10 +977,10 @@ class _AddLayerNormMixed(torch.autograd.Function):
         part = torch.empty((L.amk_rowsum_num_partials(M), 2, D), device=h.device, dtype=torch.float32)
         _lib.check(L.amk_add_layernorm_mixed_bwd(_ptr(dy2), 1 if dyb else 0, _ptr(h), _ptr(dh2), _ptr(w), _ptr(mean), _ptr(rstd),
                                                  M, D, _ptr(dh), _ptr(dh16), _ptr(part), _stream()), "amk_add_layernorm_mixed_bwd")
-        dgb = part.sum(0)
+        dw, db = _ln_param_grads(part, ctx.params)
         dhv = dh.view(shape)
         dx = dh16.view(shape) if xb else dhv
-        return dx, (dhv if has_res else None), dgb[0], dgb[1], None
+        return dx, (dhv if has_res else None), dw, db, None
 
 
 def _mixed_ln():
