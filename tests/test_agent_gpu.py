@@ -41,7 +41,10 @@ def test_agent_small_golden(device):
 
 
 @pytest.mark.parametrize("B,T,dim,h,agent_num", [(2, 10, 384, 6, 47), (1, 1024, 384, 6, 47), (2, 65, 256, 4, 16), (1, 300, 128, 2, 4), (1, 37, 64, 1, 1),
-                                                   (1, 513, 128, 2, 4), (2, 256, 192, 3, 9)])
+                                                   (1, 513, 128, 2, 4), (2, 256, 192, 3, 9),
+                                                   # 7 and 8 agents (the streaming backward's widest instantiation), 9 (the
+                                                   # LDS-staged kernels for more than 8 agents)
+                                                   (1, 200, 448, 7, 49), (2, 129, 512, 8, 64), (1, 140, 576, 9, 81)])
 def test_agent_vs_oracle(device, B, T, dim, h, agent_num):
     """README.md:116-127 shape (2,10,384) h=6, the BASELINE.md T=1024 case, ragged bins (T % p != 0),
     a last chunk of one token (513 = 2*256 + 1) and an exactly full chunk."""
