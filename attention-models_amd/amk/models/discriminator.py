@@ -83,8 +83,14 @@ class Conv2d(nn.Conv2d):
     def forward(self, x):
         if self.groups != 1 or self.dilation != (1, 1) or self.padding_mode != "zeros" or isinstance(self.padding, str):
             return super().forward(x)
-        if torch.is_autocast_enabled():  # mixed precision: ATen's own convolution autograd (dtype handling included)
-            return super().forward(x)
+        if torch.is_autocast_enabled():
+            if self.in_channels < 8 and x.is_cuda:
+                # the image layer (3 input channels) stays in f32: MIOpen's bf16 weight-gradient kernels for such a layer
+                # returned NaN from finite operands at small image sizes (tools/train_sanity.py bf16: step 3, only
+                # model.0.weight.grad non-finite); its cost is negligible (memory-bound, 0.2 % of the step's FLOP)
+                with torch.autocast("cuda", enabled=False):
+                    return _Conv.apply(x.float(), self.weight, self.bias, self.stride, self.padding)
+            return super().forward(x)  # mixed precision: ATen's own convolution autograd (dtype handling included)
         return _Conv.apply(x, self.weight, self.bias, self.stride, self.padding)
 
 

@@ -17,11 +17,18 @@ torch.manual_seed(0)
 cfg = dict(dim=128, img_size=64, patch_size=8, n_heads=2, d_head=64, depth=2, mlp_dim=256, dropout=0.0)
 model = ViTVQGAN(cfg, dict(codebook_size=512, codebook_dim=32)).to(dev)
 discr = NLayerDiscriminator(3, 32, 3).to(dev)
-tr = VQGANTrainStep(model, discr, lr=1e-3, warmup_steps=10, decay_steps=400)
+# python tools/train_sanity.py [bf16] [graph]: the same under bf16 autocast / with the step replayed as one HIP graph
+amp = torch.bfloat16 if "bf16" in sys.argv[1:] else None
+graph = "graph" in sys.argv[1:]
+tr = VQGANTrainStep(model, discr, lr=1e-3, warmup_steps=10, decay_steps=400, autocast=amp, capturable=graph)
 g = torch.Generator().manual_seed(1)
 base = torch.rand(8, 3, 8, 8, generator=g)
 imgs = torch.nn.functional.interpolate(base, size=64, mode="bilinear").to(dev)  # smooth images
 first = None
+if graph:
+    for _ in range(2):
+        tr.step(imgs)
+    tr.capture(imgs, warmup=0)
 for step in range(301):
     logs = tr.step(imgs)
     if step % 50 == 0:
