@@ -72,7 +72,8 @@ class GradReducer:
         # direct_grads: the weight-gradient kernels of amk.ops write a parameter's FIRST gradient of a step straight into its
         # (zeroed) bucket view -- claim() / wrote() below -- instead of returning a tensor for autograd to add to it: one
         # element-wise launch less per parameter and step.  For models in which a parameter meets one custom backward per
-        # step (no weight sharing between such layers); a second contribution after the bucket left raises.
+        # step (no weight sharing between such layers): a second weight-gradient kernel for the same parameter after its
+        # bucket left raises; contributions from plain autograd ops to such a parameter (weight tying) are not detected.
         self.direct_grads = bool(direct_grads) and os.environ.get("AMK_DIRECT_GRADS", "1") == "1"
         self.buckets = []
         self._bucket_of = {}
@@ -158,6 +159,11 @@ class GradReducer:
         if ent is None:
             return None
         b, i = ent
+        if b.direct[i] and b.launched and not self.alone:
+            # a second weight-gradient kernel for a parameter whose first one was written in place and whose bucket has
+            # been sent already: that contribution would miss the all-reduce
+            raise RuntimeError("GradReducer(direct_grads=True): a parameter received a second gradient after its bucket was "
+                               "sent (a weight shared between two layers?); construct with direct_grads=False")
         if b.fired[i] or b.launched or p.grad is not b.views[i]:
             return None
         return b.views[i]
@@ -171,10 +177,9 @@ class GradReducer:
     def _on_grad(self, p):
         b, i = self._bucket_of[p]
         if b.direct[i]:
-            # a further contribution through autograd after a direct write: p.grad (the view) already holds the sum
-            if b.launched and not self.alone:
-                raise RuntimeError("GradReducer(direct_grads=True): a parameter received a second gradient after its bucket "
-                                   "was sent (a weight shared between layers?); construct with direct_grads=False")
+            # counted already by wrote().  (The post-accumulate hook also runs when the backward returned None for the
+            # parameter; a genuine further contribution through plain autograd ops has been added to the view by now --
+            # in time only if the bucket has not left: weights tied to non-amk ops need direct_grads=False.)
             return
         view = b.views[i]
         if p.grad.data_ptr() != view.data_ptr():

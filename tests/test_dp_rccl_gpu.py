@@ -142,3 +142,68 @@ def test_two_ranks_share_the_gpu_over_gloo(device, tmp_path):
         assert torch.allclose(a, p.grad.cpu(), rtol=2e-5, atol=1e-6)
     for a, b in zip(r0["params"], r1["params"]):
         assert torch.equal(a, b)                                       # and take the same optimizer step
+
+
+def _two_rank_worker_mixed(rank, world, port, out_dir):
+    """The mixed-precision training path on two ranks: bf16 autocast, own bf16 GEMMs, gradients written straight into
+    the buckets (direct_grads), bf16 parameter copies refreshed by the optimizer kernel."""
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "attention-models_amd"))
+    from amk.dp import GradReducer
+    from amk.models import SoftmaxAttention
+    from amk.models.layers import LayerNorm, Linear
+    from amk.optim import FlatAdam
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dev = torch.device("cuda:0")
+    torch.cuda.set_device(dev)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.manual_seed(70 + rank)
+
+        class Block(nn.Module):
+            def __init__(self):
+                super().__init__()
+                self.norm, self.attn, self.out = LayerNorm(128), SoftmaxAttention(128, 2, 64), Linear(128, 16)
+
+            def forward(self, x):
+                return self.out(x + self.attn(self.norm(x)))
+
+        net = Block().to(dev)
+        red = GradReducer(net.parameters(), bucket_bytes=64 << 10, direct_grads=True)
+        opt = FlatAdam(red, lr=1e-2, bf16_shadow=True)
+        red.broadcast_parameters()
+        opt.refresh_shadow()          # (the broadcast wrote the parameters behind the optimizer's back)
+        g = torch.Generator().manual_seed(9)
+        x = torch.randn(4, 40, 128, generator=g)[2 * rank:2 * rank + 2].to(dev)
+        y = torch.randn(4, 40, 16, generator=g)[2 * rank:2 * rank + 2].to(dev)
+        direct = 0
+        for _ in range(3):
+            red.begin(sync=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss = ((net(x).float() - y) ** 2).mean()
+            loss.backward()
+            direct += sum(sum(b.direct) for b in red.buckets)
+            red.finish()
+            opt.step(max_norm=1.0)
+        torch.cuda.synchronize()
+        assert direct > 0, "no gradient was written in place"
+        for p in net.parameters():
+            assert torch.isfinite(p).all() and torch.equal(p._amk_bf16, p.detach().to(torch.bfloat16))
+        torch.save([p.detach().cpu().clone() for p in net.parameters()], os.path.join(out_dir, f"mixed_rank{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_mixed_precision_direct_gradients(device, tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_two_rank_worker_mixed, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = torch.load(tmp_path / "mixed_rank0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "mixed_rank1.pt", weights_only=True)
+    for a, b in zip(r0, r1):
+        assert torch.equal(a, b)      # three optimizer steps later the replicas are still identical
