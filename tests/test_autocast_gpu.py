@@ -106,3 +106,39 @@ def test_bf16_training_stays_finite_on_a_small_model(device):
         first = first if first is not None else float(logs["l2"])
     assert all(bool(torch.isfinite(p).all()) for p in list(model.parameters()) + list(discr.parameters()))
     assert float(logs["l2"]) < first
+
+
+def test_bf16_resume_and_shared_forward(device, tmp_path):
+    """Under bf16 autocast: resume_from_checkpoint refreshes the bf16 parameter copies (they equal a cast of the loaded
+    weights and are the ones the GEMMs read), and the shared-forward form of the step stays finite."""
+    from amk import ops
+    from amk.models import ViTVQGAN
+    from amk.models.discriminator import NLayerDiscriminator
+    from amk.train import VQGANTrainStep
+
+    cfg = dict(dim=128, img_size=32, patch_size=8, n_heads=2, d_head=64, depth=1, mlp_dim=256, dropout=0.0)
+    imgs = torch.rand(4, 3, 32, 32, device=device)
+
+    def make(seed, **kw):
+        torch.manual_seed(seed)
+        return VQGANTrainStep(ViTVQGAN(cfg, dict(codebook_size=64, codebook_dim=32)).to(device),
+                              NLayerDiscriminator(3, 8, 3).to(device), warmup_steps=1, autocast=torch.bfloat16, **kw)
+
+    a = make(0)
+    for _ in range(2):
+        a.step(imgs)
+    path = str(tmp_path / "ckpt.pt")
+    a.save_ckpt(path, config={"note": "test"})
+    b = make(1)
+    b.resume_from_checkpoint(path)
+    assert b.global_step == a.global_step
+    for (n, p), q in zip(b.model.named_parameters(), a.model.parameters()):
+        assert torch.equal(p, q), n
+        assert ops._w16(p) is p._amk_bf16 and torch.equal(p._amk_bf16, p.detach().to(torch.bfloat16)), n
+    logs = b.step(imgs)
+    assert all(bool(torch.isfinite(v)) for v in logs.values())
+    c = make(2, share_forward=True)
+    for _ in range(3):
+        logs = c.step(imgs)
+    assert all(bool(torch.isfinite(v)) for v in logs.values())
+    assert all(bool(torch.isfinite(p).all()) for p in c.model.parameters())
