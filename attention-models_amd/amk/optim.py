@@ -64,6 +64,8 @@ class FlatAdam:
             self.seg.append(seg.to(dev))
         if bf16_shadow:
             self.enable_shadow()
+        else:
+            self.disable_shadow()   # (copies a deepcopy of a model may have carried over from another optimizer: stale)
         self.partials = torch.zeros(len(reducer.buckets) * self.npart, device=dev, dtype=torch.float32)
         self.norm = torch.zeros(1, device=dev, dtype=torch.float32)
         # per-step table {active, lr / bc1, sqrt(bc2), 0} per parameter: pinned host staging, async copy
@@ -90,9 +92,8 @@ class FlatAdam:
 
     def disable_shadow(self):
         for p in self.params:
-            if hasattr(p, "_amk_bf16"):
-                del p._amk_bf16
-                del p._amk_bf16_version
+            p.__dict__.pop("_amk_bf16", None)
+            p.__dict__.pop("_amk_bf16_version", None)
         self.flat_p16 = []
 
     def refresh_shadow(self):
