@@ -1036,6 +1036,10 @@ using namespace amk_agent;
 
 static bool a16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static bool sok(const Strides& s) { return s.sb % 4 == 0 && s.st % 4 == 0 && s.sh % 4 == 0; }
+// the kernels address one batch entry's (h, T, d) slab through a 32-bit byte offset (offsets from 2^31 on mean "past the end")
+static bool span_ok(const Strides& s, int H, int T) {
+  return s.st >= 0 && s.sh >= 0 && ((int64_t)(H - 1) * s.sh + (int64_t)(T - 1) * s.st + D) * 4 < 0x7ffffffell;
+}
 static int nchunks(int T) { return (T + CH - 1) / CH; }
 
 // kernels are instantiated for up to 8 and up to 16 agents per head (register arrays sized to that)
@@ -1073,6 +1077,8 @@ extern "C" int amk_agent_attn_fwd(const float* q, const float* k, const float* v
                 "amk_agent_attn_fwd: pointers must be 16-byte aligned and strides multiples of 4");
   const int64_t cells = (int64_t)B * H * p.NC;
   AMK_CHECK_SUPPORTED(cells * P < (1ll << 31), "amk_agent_attn_fwd: B*h*chunks*p exceeds the grid limit");
+  AMK_CHECK_SUPPORTED(span_ok(p.qs, H, T) && span_ok(p.ks, H, T) && span_ok(p.vs, H, T) && span_ok(p.os, H, T),
+                      "amk_agent_attn_fwd: one batch entry of a tensor must span less than 2 GiB with non-negative strides");
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(agent_pool_kernel, dim3((unsigned)(B * H * P)), dim3(NT), 0, st, p);
   AMK_AGENT_LAUNCH(agent_s1_partial_kernel, P, dim3((unsigned)cells), dim3(NT), 0, st, p);
@@ -1109,6 +1115,9 @@ extern "C" int amk_agent_attn_bwd(const float* q, const float* k, const float* v
                 "amk_agent_attn_bwd: pointers must be 16-byte aligned and strides multiples of 4");
   const int64_t pblk = (int64_t)B * H * ((T + PB - 1) / PB);
   AMK_CHECK_SUPPORTED(pblk < (1ll << 31), "amk_agent_attn_bwd: B*h*T exceeds the grid limit");
+  AMK_CHECK_SUPPORTED(span_ok(p.qs, H, T) && span_ok(p.ks, H, T) && span_ok(p.vs, H, T) && span_ok(p.dos, H, T) &&
+                          span_ok(p.dqs, H, T) && span_ok(p.dks, H, T) && span_ok(p.dvs, H, T),
+                      "amk_agent_attn_bwd: one batch entry of a tensor must span less than 2 GiB with non-negative strides");
   hipStream_t st = static_cast<hipStream_t>(stream);
   static int stream_mode = -1;   // AMK_AGENT_STREAM=0: the LDS-staged chunk kernels also for P <= 8
   if (stream_mode < 0) {

@@ -202,6 +202,7 @@ def test_hip_graph_capture_of_a_train_step(device):
     assert_close(l_g, l_e, 1e-4, "loss at the 6th step")
     for (n, a), (_, b) in zip(eager.named_parameters(), graphed.named_parameters()):
         if a.grad is not None:
+            a, b = a.detach(), b.detach()
             assert float((a - b).abs().max()) <= 1e-4 * max(1.0, float(a.abs().max())), n
 
 
