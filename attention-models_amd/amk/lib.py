@@ -97,6 +97,7 @@ SIGNATURES = {
     "amk_grouped_gemm_nn_acc": (_I, [_P, _L, _I, _P, _P, _P, _P, _L, _I, _I, _I, _P, _I, _P]),
     "amk_grouped_gemm_wgrad": (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     "amk_moe_combine": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "amk_moe_expert_sums": (_I, [_P, _L, _I, _P, _P, _L, _I, _I, _I, _P, _P]),
     "amk_moe_gate_grad": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
 }
 

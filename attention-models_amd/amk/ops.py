@@ -573,6 +573,29 @@ def moe_route(logits2, k):
 MOE_SUM_IN_GEMM = os.environ.get("AMK_MOE_SUM_IN_GEMM", "0") == "1"
 
 
+# Where a row sums many pairs -- SwitchHead: 8 heads x top-2 = 16 pairs per token over 32 experts -- the sum over the pairs
+# of (pair row) x (its expert's matrix) is one dense product of the per-expert sums of the pair rows, Z (G, E*d), with the
+# stacked expert matrices (E*d, N): E/fan times the routed FLOPs, but no (pairs, N) intermediate to write and re-read
+# (272 MB per launch at the ViTMoE layer).  Measured there: 0.147 + 0.074 ms (routed GEMM + combine) against
+# ~0.17 ms (sums + dense GEMM), and 0.163 + 0.074 against ~0.155 for the V experts' input gradient.  The sums differ
+# from the ordered combine in accumulation order only; both are reproducible.  AMK_MOE_DENSE_Z=0: the routed form.
+MOE_DENSE_Z = os.environ.get("AMK_MOE_DENSE_Z", "1") != "0"
+
+
+def _moe_dense_z(width, depth, fan, E):
+    """width: output row length; depth: contraction length per pair; fan: pairs per output row; E experts."""
+    return MOE_DENSE_Z and E <= 2 * fan and width >= 256 and width >= 4 * depth and depth % 4 == 0
+
+
+def _expert_sums(a2, a_div, ids, scale, G, fan, E, d):
+    """Z (G, E*d): per output row and expert, the (scaled) sum of the rows of a2 its pairs read."""
+    Z = torch.empty((G, E * d), device=a2.device, dtype=torch.float32)
+    with _timed(f"moe_expert_sums G{G} fan{fan} E{E} d{d}"):
+        rc = _lib.load().amk_moe_expert_sums(_ptr(a2), a2.stride(0), a_div, _ptr(ids), scale, G, fan, E, d, _ptr(Z), _stream())
+    _lib.check(rc, "amk_moe_expert_sums")
+    return Z
+
+
 def _moe_sum_in_gemm(width, depth, fan):
     """width: output row length; depth: contraction length; fan: pairs per output row."""
     if not MOE_SUM_IN_GEMM or DETERMINISTIC_ATTENTION_BACKWARD or torch.are_deterministic_algorithms_enabled():
@@ -604,7 +627,12 @@ class _RoutedLinear(torch.autograd.Function):
             r = moe_route(logits2.detach(), k)
         L = _lib.load()
         G = U // outer
-        if not weighted and _moe_sum_in_gemm(N, Kd, outer * k):
+        if not weighted and bias is None and _moe_dense_z(N, Kd, outer * k, E):
+            Y = None
+            Z = _expert_sums(x2, x_div, r["ids"], _NULL, G, outer * k, E, Kd)
+            with _timed(f"dense_z_gemm M{G} N{N} K{E * Kd}"):
+                out = Z @ W.permute(0, 2, 1).reshape(E * Kd, N)   # (E, N, Kd) -> (E*Kd, N): an 8 MB copy at the ViTMoE layer
+        elif not weighted and _moe_sum_in_gemm(N, Kd, outer * k):
             # un-weighted sum over the pairs of an output row (SwitchHead's output experts): folded into the GEMM's
             # epilogue -- the (P, N) per-pair intermediate (272 MB at the ViTMoE layer) is never written
             Y = None
@@ -647,7 +675,15 @@ class _RoutedLinear(torch.autograd.Function):
             dlogits = torch.empty((U, E), device=dev, dtype=torch.float32)
             rc = L.amk_moe_gate_grad(_ptr(d_out), _ptr(Y), _ptr(ids), _ptr(gate), P, k, E, N, g_div, _ptr(dlogits), _stream())
             _lib.check(rc, "amk_moe_gate_grad")
-        if _moe_sum_in_gemm(Kd, N, x_div):
+        if not ctx.needs_input_grad[0]:
+            dx = None
+        elif _moe_dense_z(Kd, N, x_div, E):
+            # dx[r] = sum over the x_div pairs of input row r of scale * dOut-row x W[e] (N, Kd): per-expert sums of the
+            # dOut rows, then one product with W viewed as (E*N, Kd) -- no copy
+            Z = _expert_sums(d_out, g_div, ids, scale, x2.shape[0], x_div, E, N)
+            with _timed(f"dense_z_gemm M{x2.shape[0]} N{Kd} K{E * N}"):
+                dx = Z @ W.view(E * N, Kd)
+        elif _moe_sum_in_gemm(Kd, N, x_div):
             # the input rows' gradients are sums over the x_div pairs that read them: folded into the GEMM's epilogue
             dx = torch.zeros_like(x2)
             with _timed(f"grouped_nn_acc P{P} N{N} K{Kd}"):

@@ -1179,6 +1179,36 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
   st4(out + gi * N + c, tot);
 }
 
+// Z[g, e, :] = sum over the fan pairs of row g (p = g*fan + j) that chose expert e of scale[p] * A[p / a_div, :].
+// With Z in hand the sum over a row's pairs of (pair row) x (its expert's matrix) is ONE dense product
+// Z (G, E*d) x (E*d, N): no (pairs, N) intermediate.  One workgroup per row; a thread owns float4s of the row and walks
+// the row's pairs in order (a fixed order: the result is reproducible).
+__global__ __launch_bounds__(256) void expert_sums_kernel(const float* __restrict__ A, int64_t lda, int a_div,
+                                                          const int64_t* __restrict__ ids, const float* __restrict__ scale,
+                                                          int fan, int E, int d, float* __restrict__ Z) {
+  extern __shared__ int es_lds[];
+  int* sid = es_lds;                                   // [fan] expert of pair j
+  float* ssc = reinterpret_cast<float*>(es_lds + fan); // [fan] its scale
+  const int64_t g = blockIdx.x, p0 = g * fan;
+  for (int j = threadIdx.x; j < fan; j += 256) {
+    sid[j] = (int)ids[p0 + j];
+    ssc[j] = scale ? scale[p0 + j] : 1.f;
+  }
+  __syncthreads();
+  const int dv = d >> 2, nv = E * dv;
+  for (int idx = threadIdx.x; idx < nv; idx += 256) {
+    const int e = idx / dv, c = (idx - e * dv) * 4;
+    float4 acc = zero4();
+    for (int j = 0; j < fan; ++j)
+      if (sid[j] == e) {
+        const float w = ssc[j];
+        const float4 a = ld4(A + ((p0 + j) / a_div) * lda + c);
+        acc.x += w * a.x; acc.y += w * a.y; acc.z += w * a.z; acc.w += w * a.w;
+      }
+    st4(Z + g * (int64_t)E * d + (int64_t)idx * 4, acc);
+  }
+}
+
 // dlogits[u, ids[p]] = gate[p]*(1-gate[p]) * <dOut[p / g_div, :], Y[p, :]>   (dlogits zeroed by the caller side)
 __global__ __launch_bounds__(256) void gate_grad_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                         const int64_t* __restrict__ ids, const float* __restrict__ gate,
@@ -1390,6 +1420,18 @@ extern "C" int amk_moe_combine(const float* Y, const int64_t* ids, const float* 
   hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
                      Y, ids, scale, G, outer, k, N, out);
   AMK_CHECK_LAUNCH("amk_moe_combine");
+  return AMK_OK;
+}
+
+extern "C" int amk_moe_expert_sums(const float* A, int64_t lda, int a_div, const int64_t* ids, const float* scale,
+                                   int64_t G, int fan, int E, int d, float* Z, void* stream) {
+  AMK_CHECK_ARG(A && ids && Z, "amk_moe_expert_sums: null pointer");
+  AMK_CHECK_ARG(G > 0 && fan > 0 && E > 0 && d > 0 && a_div > 0 && lda >= d, "amk_moe_expert_sums: non-positive size");
+  AMK_CHECK_SUPPORTED(d % 4 == 0 && lda % 4 == 0 && a16(A) && a16(Z) && fan <= 4096 && G < (1ll << 31),
+                      "amk_moe_expert_sums: d, lda multiples of 4, aligned pointers, fan <= 4096");
+  hipLaunchKernelGGL(expert_sums_kernel, dim3((unsigned)G), dim3(256), (size_t)fan * 8, static_cast<hipStream_t>(stream),
+                     A, lda, a_div, ids, scale, fan, E, d, Z);
+  AMK_CHECK_LAUNCH("amk_moe_expert_sums");
   return AMK_OK;
 }
 

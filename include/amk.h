@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 132 /* 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
+#define AMK_VERSION 133 /* 0.3.3: amk_moe_expert_sums; 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
 
 enum {
   AMK_OK = 0,
@@ -280,6 +280,15 @@ int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, const float* 
  * head sum of switchhead_attention.py:115.  scale (G*outer*k) or NULL (moe_out is un-weighted). */
 int amk_moe_combine(const float* Y, const int64_t* ids, const float* scale, int64_t G, int outer, int k,
                     int N, float* out, void* stream);
+
+/* Z[g, e, :] = sum over the fan pairs of row g (pairs g*fan .. g*fan+fan-1) that chose expert e = ids[p] of
+ * scale[p] * A[p / a_div, :]  (d floats at stride lda; scale (G*fan) or NULL).  Z (G, E*d) is fully overwritten, in a
+ * fixed order.  With it the head / slot sum of SwitchHead's output experts (switchhead_attention.py:86-87,115) is one
+ * dense product Z x (E*d, N) instead of amk_grouped_gemm_nt + amk_moe_combine and their (pairs, N) intermediate, and
+ * likewise the input gradient of its V experts (switchhead_attention.py:69-71) -- worth it where a row has at least
+ * E/2 pairs (the dense product does E/fan times the routed FLOPs).  d, lda multiples of 4; fan <= 4096. */
+int amk_moe_expert_sums(const float* A, int64_t lda, int a_div, const int64_t* ids, const float* scale,
+                        int64_t G, int fan, int E, int d, float* Z, void* stream);
 
 /* Gradient of the gate logits through sigmoid(topk): dlogits (P/k, E) is zeroed, then
  * dlogits[p/k, ids[p]] = gate[p]*(1-gate[p]) * <d_out[p / g_div, :], Y[p, :]>. */

@@ -130,11 +130,16 @@ def test_switchhead_small_golden(device, variant):
             assert_close_abs(g, torch.from_numpy(fx[key]), TOL, n)
 
 
+@pytest.mark.parametrize("dense_z", [True, False], ids=["dense_z", "routed"])
 @pytest.mark.parametrize("B,T,dim,h,E,k", [(2, 65, 1024, 8, 32, 2), (2, 65, 1024, 8, 5, 2), (1, 10, 512, 2, 5, 2)])
-def test_switchhead_vs_oracle(device, B, T, dim, h, E, k):
-    """ViTMoE layer dims (E 32 through the factory, E 5 standalone default) and README.md:133-142."""
+def test_switchhead_vs_oracle(device, monkeypatch, B, T, dim, h, E, k, dense_z):
+    """ViTMoE layer dims (E 32 through the factory, E 5 standalone default) and README.md:133-142; the head / slot sums
+    as one dense product over per-expert sums (the default at these sizes) and as routed GEMM + ordered combine."""
+    from amk import ops
     from amk.models import SwitchHeadAttention
 
+    monkeypatch.setattr(ops, "MOE_DENSE_Z", dense_z)
+    assert ops._moe_dense_z(dim, 64, h * k, E) == dense_z
     d = 64
     shapes = {"q.0.weight": (h * d, dim), "k.0.weight": (h * d, dim), "W_s.0.weight": (h * E, dim), "W_d.0.weight": (h * E, dim)}
     for e in range(E):
@@ -190,3 +195,22 @@ def test_routing_properties_full_size(device, U, E, k):
         seg = perm[offsets[e]:offsets[e + 1]]
         assert bool((flat[seg] == e).all())
         assert bool((seg[1:] > seg[:-1]).all())
+
+
+@pytest.mark.parametrize("G,fan,a_div,E,d,weighted", [(37, 16, 2, 32, 64, False), (5, 6, 3, 4, 8, True), (1, 1, 1, 1, 4, True),
+                                                       (130, 300, 1, 7, 20, True)])
+def test_expert_sums(device, G, fan, a_div, E, d, weighted):
+    """amk_moe_expert_sums against an index_add over the pairs (float64)."""
+    from amk import ops
+
+    g = torch.Generator().manual_seed(G * 31 + fan)
+    P = G * fan
+    rows = (P + a_div - 1) // a_div
+    A = torch.randn(rows, d + 4, generator=g).to(device)[:, :d]   # rows at a stride larger than d
+    ids = torch.randint(0, E, (P,), generator=g).to(device)
+    scale = torch.rand(P, generator=g).to(device) if weighted else None
+    Z = ops._expert_sums(A, a_div, ids, ops._ptr(scale) if weighted else ops._NULL, G, fan, E, d)
+    p = torch.arange(P, device=device)
+    src = A.double()[p // a_div] * (scale.double()[:, None] if weighted else 1.0)
+    ref = torch.zeros(G * E, d, dtype=torch.float64, device=device).index_add_(0, (p // fan) * E + ids, src)
+    assert_close(Z.view(G * E, d), ref.float(), 2e-6, "expert sums")
