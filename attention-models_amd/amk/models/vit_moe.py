@@ -31,8 +31,20 @@ class Encoder(nn.Module):
                                     for _ in range(depth))
 
     def forward(self, x, context_mask=None):
-        for layer in self.layers:
-            x = layer(x, context_mask=context_mask)
+        # the layers' arithmetic (EncoderLayer.forward) with every residual add inside the kernel of the LayerNorm that
+        # follows it: (x + branch, LN(x + branch)) from one launch, and one launch for both in the backward
+        layers = self.layers
+        if len(layers) == 0:
+            return x
+        n = layers[0].norm1(x)
+        for i, layer in enumerate(layers):
+            a = layer.self_attn(x=n, context_mask=context_mask)
+            x, n = layer.norm2(a, residual=x)
+            m = layer.moe(n)
+            if i + 1 < len(layers):
+                x, n = layers[i + 1].norm1(m, residual=x)
+            else:
+                x = m + x
         return x
 
 

@@ -655,11 +655,14 @@ class _RoutedLinear(torch.autograd.Function):
         ctx.save_for_backward(x2, W, Y, r["ids"], r["gate"], r["offsets"], r["perm"])
         ctx.cfg = (k, x_div, weighted, outer, E, bias is not None)
         ctx.mark_non_differentiable(r["ids"])
+        ctx.set_materialize_grads(False)   # no zero-filled "gradient" of the ids handed to backward
         return out, r["ids"]
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, d_out, _d_ids):
+        if d_out is None:
+            return (None,) * 8
         x2, W, Y, ids, gate, offsets, perm = ctx.saved_tensors
         k, x_div, weighted, outer, E, has_bias = ctx.cfg
         N, Kd = W.shape[1], W.shape[2]
