@@ -99,11 +99,14 @@ class SwitchHeadAttention(StackedExpertsMixin, nn.Module):
             raise NotImplementedError("SwitchHeadAttention with a context of another length is a reference quirk, not supported")
         h, d, E, k = self.num_heads, self.dim_head, self.num_experts, self.sel_experts
         if context is None and not (self.dropout_p > 0.0 and self.training):
-            # self-attention: q, k and both gate projections read the same rows -> one GEMM over the
-            # stacked weights (four launches and four passes over x otherwise).  W_d only selects
-            # experts (top-k indices), so it stays without a gradient, as in the reference.
-            W = torch.cat([self.q[0].weight, self.k[0].weight, self.W_s[0].weight, self.W_d[0].weight.detach()], 0)
-            q2, k2, gate_s, gate_d = F.linear(x, W).split([h * d, h * d, h * E, h * E], dim=-1)
+            # self-attention: q, k and the V experts' gate projection read the same rows -> one GEMM over the
+            # stacked weights (three launches and three passes over x otherwise, each way).  W_d only selects
+            # experts (top-k indices), so it stays without a gradient, as in the reference -- and out of the stacked
+            # GEMM, whose backward would otherwise spend a sixth of its two products on columns of zeros.
+            W = torch.cat([self.q[0].weight, self.k[0].weight, self.W_s[0].weight], 0)
+            q2, k2, gate_s = F.linear(x, W).split([h * d, h * d, h * E], dim=-1)
+            with torch.no_grad():
+                gate_d = F.linear(x, self.W_d[0].weight)
             q = q2.view(B, I, h, d).permute(0, 2, 1, 3)       # strided views of the GEMM output, no copies
             kk = k2.view(B, J, h, d).permute(0, 2, 1, 3)
         else:
