@@ -288,6 +288,13 @@ def vitmoe_block(dev, batch=64, steps=3):
         if m:
             fl = 2.0 * int(m.group(1)) * int(m.group(2)) * int(m.group(3))
             r.update(flop=fl, tflops=fl / (ms * 1e-3) / 1e12, frac_of_f32_mfma_peak=fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS)
+        m = re.match(r"dense_z_gemm M(\d+) N(\d+) K(\d+)", name)
+        if m:
+            # SwitchHead's head / slot sums as one library GEMM over per-expert sums: the FLOPs it EXECUTES (E / pairs-per-row
+            # = 2x the routed ones at this layer), so the fraction is the GEMM's own efficiency
+            fl = 2.0 * int(m.group(1)) * int(m.group(2)) * int(m.group(3))
+            r.update(flop=fl, note="executed FLOPs of the dense form (2x the routed ones); vendor GEMM",
+                     tflops=fl / (ms * 1e-3) / 1e12, frac_of_f32_mfma_peak=fl / (ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS)
         rows.append(r)
     del vm
     torch.cuda.empty_cache()

@@ -18,11 +18,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--no-tune", action="store_true", help="library GEMMs without TunableOp (keeps its trial kernels out of a profile)")
     a = ap.parse_args()
     from amk import tuning
     from amk.models import ViTMoE
 
-    tuning.enable_gemm_tuning()   # as bench.py: TunableOp's selection for the GEMMs left on the library
+    if not a.no_tune:
+        tuning.enable_gemm_tuning()   # as bench.py: TunableOp's selection for the GEMMs left on the library
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     vm = ViTMoE(dim=1024, image_size=256, patch_size=32, n_heads=8, d_head=64, depth=6, n_experts=32, sel_experts=2,
