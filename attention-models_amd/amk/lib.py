@@ -98,6 +98,10 @@ SIGNATURES = {
     "amk_grouped_gemm_wgrad": (_I, [_P, _L, _I, _P, _L, _I, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P]),
     "amk_moe_combine": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "amk_moe_expert_sums": (_I, [_P, _L, _I, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "amk_moe_topk": (_I, [_P, _L, _I, _I, _P, _P, _P]),
+    "amk_moe_route_distinct": (_I, [_P, _L, _I, _I, _P, _P, _P, _P]),
+    "amk_moe_combine_rows": (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "amk_moe_gate_grad_rows": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "amk_moe_gate_grad": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _P]),
 }
 

@@ -114,15 +114,24 @@ class SwitchHeadAttention(StackedExpertsMixin, nn.Module):
             kk = self._drop(self.k(src)).view(B, J, h, d).permute(0, 2, 1, 3)
             gate_s, gate_d = self.W_s(src), self.W_d(src)
         src2 = src.reshape(B * J, self.dim)
+        # where a token's h*k pairs cover at least half of the experts, an expert's product is formed once per distinct
+        # (token, expert) and the head / slot sums are dense products over per-expert sums (ops._SharedRowExperts)
+        distinct = ops.distinct_experts_ok(self.dim, d, h * k, E, src2, self.experts_v_weight, self.experts_out_weight)
         # moe_v: unit = (b, t, head); every unit reads the token's full input row
-        v, sel_v = ops.routed_linear(src2, gate_s.reshape(B * J * h, E), self.experts_v_weight, None,
-                                     k, x_div=h * k, weighted=True, outer=1)
+        if distinct:
+            v, sel_v = ops.shared_row_experts(src2, gate_s.reshape(B * J * h, E), self.experts_v_weight, k, h)
+        else:
+            v, sel_v = ops.routed_linear(src2, gate_s.reshape(B * J * h, E), self.experts_v_weight, None,
+                                         k, x_div=h * k, weighted=True, outer=1)
         v = v.view(B, J, h, d).permute(0, 2, 1, 3)
         o = ops.attention(q, kk, v, self.scale, key_mask=context_mask, causal_mask=causal_mask)  # (B,h,I,d)
         o2 = o.permute(0, 2, 1, 3).reshape(B * I * h, d)  # 'b i h d' rows, contiguous by construction
         # moe_out: routed by W_d(gate_inputs = src), experts summed un-weighted, then summed over heads
-        out, sel_o = ops.routed_linear(o2, gate_d.reshape(B * J * h, E), self.experts_out_weight, None,
-                                       k, x_div=k, weighted=False, outer=h)
+        if distinct:
+            out, sel_o = ops.summed_experts(o2, gate_d.reshape(B * J * h, E), self.experts_out_weight, k, h)
+        else:
+            out, sel_o = ops.routed_linear(o2, gate_d.reshape(B * J * h, E), self.experts_out_weight, None,
+                                           k, x_div=k, weighted=False, outer=h)
         self.last_selected_v = sel_v.view(B, J, h, k)
         self.last_selected_out = sel_o.view(B, J, h, k)
         return out.view(B, I, self.dim)

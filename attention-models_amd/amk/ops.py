@@ -715,6 +715,156 @@ def routed_linear(x2, logits2, W, bias, k, x_div, weighted=True, outer=1):
     return _RoutedLinear.apply(x2, logits2, W, bias, k, x_div, weighted, outer)
 
 
+def _topk(logits2, k):
+    """(ids int64 (U,k), gate (U,k)): amk_moe_route's selection stage alone."""
+    U, E = logits2.shape
+    ids = torch.empty((U, k), device=logits2.device, dtype=torch.int64)
+    gate = torch.empty((U, k), device=logits2.device, dtype=torch.float32)
+    _lib.check(_lib.load().amk_moe_topk(_ptr(logits2.contiguous()), U, E, k, _ptr(ids), _ptr(gate), _stream()), "amk_moe_topk")
+    return ids, gate
+
+
+def _route_distinct(ids, G, fan, E):
+    """(offsets (E+1), perm): the distinct (row group, expert) combinations as virtual pairs g*E + e, by expert."""
+    dev = ids.device
+    mask = torch.empty((G,), device=dev, dtype=torch.int64)
+    offsets, perm = _i32(E + 1, dev), _i32(G * min(fan, E), dev)
+    _lib.check(_lib.load().amk_moe_route_distinct(_ptr(ids), G, fan, E, _ptr(mask), _ptr(offsets), _ptr(perm), _stream()),
+               "amk_moe_route_distinct")
+    return offsets, perm
+
+
+def distinct_experts_ok(dim, d, fan, E, *weights):
+    """The SwitchHead forms below apply: a token's fan = h*k pairs are at least E/2, at most 64 experts, model rows at least
+    256 wide and 4x the head dim (ops._moe_dense_z), everything on the GPU."""
+    return E <= 64 and _moe_dense_z(dim, d, fan, E) and dim % 4 == 0 and all(w.is_cuda for w in weights)
+
+
+class _SharedRowExperts(torch.autograd.Function):
+    """SwitchHead's V experts (reference switchhead_attention.py:58-73): U = G*H units, the H units (heads) of group g
+    (token) all read x row g; out[u] = sum over the unit's k slots of gate * x[g] W[e]^T.  The product x[g] W[e]^T does not
+    depend on the head, so it is formed once per DISTINCT (token, expert) -- amk_moe_route_distinct's lists feed the same
+    grouped GEMMs -- and fanned out to the units that chose it; backward: per-expert sums of the (gated) output gradients,
+    then dx as one dense product and dW from the distinct rows.  Returns (out (U, N), ids (U, k))."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, x2, logits2, W, k, H):
+        _require_device(x2, logits2, W)
+        x2, W = x2.contiguous(), W.contiguous()
+        U, E = logits2.shape
+        N, Kd = W.shape[1], W.shape[2]
+        G, fan = U // H, H * k
+        if x2.shape != (G, Kd) or U % H:
+            raise RuntimeError(f"shared-row experts: shapes disagree: x {tuple(x2.shape)} U {U} H {H} W {tuple(W.shape)}")
+        L = _lib.load()
+        with _timed(f"moe_topk U{U} E{E} k{k} + distinct lists"):
+            ids, gate = _topk(logits2.detach(), k)
+            offsets, perm = _route_distinct(ids, G, fan, E)
+        V = torch.empty((G * E, N), device=x2.device, dtype=torch.float32)   # rows of chosen (token, expert) only
+        with _timed(f"grouped_nt P{U * k} N{N} K{Kd} (distinct rows)"):
+            _lib.check(L.amk_grouped_gemm_nt(_ptr(x2), Kd, E, _ptr(W), _NULL, _ptr(offsets), _ptr(perm), G * E, E, N, Kd, _ptr(V),
+                                             _stream()), "amk_grouped_gemm_nt")
+        out = torch.empty((U, N), device=x2.device, dtype=torch.float32)
+        _lib.check(L.amk_moe_combine_rows(_ptr(V), _ptr(ids), _ptr(gate), U, 1, k, N, fan, E, _ptr(out), _stream()),
+                   "amk_moe_combine_rows")
+        ctx.save_for_backward(x2, W, V, ids, gate, offsets, perm)
+        ctx.cfg = (k, H)
+        ctx.mark_non_differentiable(ids)
+        ctx.set_materialize_grads(False)
+        return out, ids
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, d_out, _d_ids):
+        if d_out is None:
+            return (None,) * 5
+        x2, W, V, ids, gate, offsets, perm = ctx.saved_tensors
+        k, H = ctx.cfg
+        E, N, Kd = W.shape
+        G, fan = x2.shape[0], H * k
+        U = G * H
+        d_out = d_out.contiguous()
+        L = _lib.load()
+        dlogits = torch.empty((U, E), device=x2.device, dtype=torch.float32)
+        _lib.check(L.amk_moe_gate_grad_rows(_ptr(d_out), _ptr(V), _ptr(ids), _ptr(gate), U * k, k, E, N, k, fan, _ptr(dlogits),
+                                            _stream()), "amk_moe_gate_grad_rows")
+        Z = _expert_sums(d_out, k, ids, _ptr(gate), G, fan, E, N)      # (G, E*N): gated output gradients per (token, expert)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            with _timed(f"dense_z_gemm M{G} N{Kd} K{E * N}"):
+                dx = Z @ W.view(E * N, Kd)
+        dW = torch.empty_like(W)
+        with _timed(f"grouped_wgrad P{U * k} N{N} K{Kd} (distinct rows)"):
+            _lib.check(L.amk_grouped_gemm_wgrad(_ptr(Z), N, 1, _ptr(x2), Kd, E, _NULL, _ptr(offsets), _ptr(perm), G * E, E, N, Kd,
+                                                _ptr(dW), _NULL, _stream()), "amk_grouped_gemm_wgrad")
+        return dx, dlogits, dW, None, None
+
+
+class _SummedExperts(torch.autograd.Function):
+    """SwitchHead's output experts + head sum (reference switchhead_attention.py:75-88,115): U = G*H units with their own
+    rows a2[u]; out[g] = sum over the group's H*k pairs of a2[u] W[e]^T, un-weighted.  Forward: per-expert sums of the rows,
+    one dense product.  Backward: d_out[g] W[e] once per distinct (token, expert), fanned out to the units; dW from the
+    distinct rows of the forward's sums.  Returns (out (G, N), ids (U, k)); the logits get no gradient (un-weighted)."""
+
+    @staticmethod
+    @_amp_fwd
+    def forward(ctx, a2, logits2, W, k, H):
+        _require_device(a2, logits2, W)
+        a2, W = a2.contiguous(), W.contiguous()
+        U, E = logits2.shape
+        N, Kd = W.shape[1], W.shape[2]
+        G, fan = U // H, H * k
+        if a2.shape != (U, Kd) or U % H:
+            raise RuntimeError(f"summed experts: shapes disagree: a {tuple(a2.shape)} U {U} H {H} W {tuple(W.shape)}")
+        with _timed(f"moe_topk U{U} E{E} k{k}"):
+            ids, _gate = _topk(logits2.detach(), k)
+        Z = _expert_sums(a2, k, ids, _NULL, G, fan, E, Kd)
+        with _timed(f"dense_z_gemm M{G} N{N} K{E * Kd}"):
+            out = Z @ W.permute(0, 2, 1).reshape(E * Kd, N)
+        ctx.save_for_backward(W, Z, ids)
+        ctx.cfg = (k, H)
+        ctx.mark_non_differentiable(ids)
+        ctx.set_materialize_grads(False)
+        return out, ids
+
+    @staticmethod
+    @_amp_bwd
+    def backward(ctx, d_out, _d_ids):
+        if d_out is None:
+            return (None,) * 5
+        W, Z, ids = ctx.saved_tensors
+        k, H = ctx.cfg
+        E, N, Kd = W.shape
+        G, fan = Z.shape[0], H * k
+        U = G * H
+        d_out = d_out.contiguous()
+        L = _lib.load()
+        offsets, perm = _route_distinct(ids, G, fan, E)
+        da = None
+        if ctx.needs_input_grad[0]:
+            D = torch.empty((G * E, Kd), device=W.device, dtype=torch.float32)
+            with _timed(f"grouped_nn P{U * k} N{N} K{Kd} (distinct rows)"):
+                _lib.check(L.amk_grouped_gemm_nn(_ptr(d_out), N, E, _ptr(W), _NULL, _ptr(offsets), _ptr(perm), G * E, E, N, Kd, _ptr(D),
+                                                 _stream()), "amk_grouped_gemm_nn")
+            da = torch.empty((U, Kd), device=W.device, dtype=torch.float32)
+            _lib.check(L.amk_moe_combine_rows(_ptr(D), _ptr(ids), _NULL, U, 1, k, Kd, fan, E, _ptr(da), _stream()),
+                       "amk_moe_combine_rows")
+        dW = torch.empty_like(W)
+        with _timed(f"grouped_wgrad P{U * k} N{N} K{Kd} (distinct rows)"):
+            _lib.check(L.amk_grouped_gemm_wgrad(_ptr(d_out), N, E, _ptr(Z), Kd, 1, _NULL, _ptr(offsets), _ptr(perm), G * E, E, N, Kd,
+                                                _ptr(dW), _NULL, _stream()), "amk_grouped_gemm_wgrad")
+        return da, None, dW, None, None
+
+
+def shared_row_experts(x2, logits2, W, k, H):
+    return _SharedRowExperts.apply(x2, logits2, W, k, H)
+
+
+def summed_experts(a2, logits2, W, k, H):
+    return _SummedExperts.apply(a2, logits2, W, k, H)
+
+
 # ---------------------------------------------------------------------------- agent attention
 class _AgentAttn(torch.autograd.Function):
     """qkv (B,T,3*h*d) with the reference's '(qkv h d)' column order -> o (B,T,h*d)."""

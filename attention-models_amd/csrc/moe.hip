@@ -1145,9 +1145,11 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g
 // ---------------------------------------------------------------------------------------
 // out[g, :] = sum_{o < outer} ( sum over the k slots of unit (g*outer+o), ascending expert id,
 //             of scale[p] * Y[p, :] )     -- the accumulation order of the reference loops.
+// v_div > 0: Y is laid out per (row group, expert) -- pair p reads row (p / v_div) * E + ids[p] (the products of
+// amk_moe_route_distinct's lists, computed once per distinct (group, expert)); v_div == 0: row p.
 __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ Y, const int64_t* __restrict__ ids,
                                                       const float* __restrict__ scale, int64_t G, int outer, int k,
-                                                      int N, float* __restrict__ out) {
+                                                      int N, int v_div, int E, float* __restrict__ out) {
   const int nv = N >> 2;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= G * nv) return;
@@ -1166,7 +1168,7 @@ __global__ __launch_bounds__(256) void combine_kernel(const float* __restrict__ 
     for (int s = 0; s < k; ++s) {
       const int64_t p = u * k + order[s];
       const float w = scale ? scale[p] : 1.f;
-      const float4 y = ld4(Y + p * N + c);
+      const float4 y = ld4(Y + (v_div ? (p / v_div) * E + ids[p] : p) * N + c);
       // res += w * y with separate rounding of the product, as the eager reference does
       acc.x = __fadd_rn(acc.x, __fmul_rn(w, y.x));
       acc.y = __fadd_rn(acc.y, __fmul_rn(w, y.y));
@@ -1212,15 +1214,15 @@ __global__ __launch_bounds__(256) void expert_sums_kernel(const float* __restric
 // dlogits[u, ids[p]] = gate[p]*(1-gate[p]) * <dOut[p / g_div, :], Y[p, :]>   (dlogits zeroed by the caller side)
 __global__ __launch_bounds__(256) void gate_grad_kernel(const float* __restrict__ dOut, const float* __restrict__ Y,
                                                         const int64_t* __restrict__ ids, const float* __restrict__ gate,
-                                                        int64_t P, int k, int E, int N, int g_div,
+                                                        int64_t P, int k, int E, int N, int g_div, int v_div,
                                                         float* __restrict__ dlogits) {
-  // 16 lanes per pair
+  // 16 lanes per pair; v_div > 0: Y rows per (row group, expert) as in combine_kernel
   const int64_t p = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
   const int l = threadIdx.x & 15;
   float acc = 0.f;
   if (p < P) {
     const float* a = dOut + (p / g_div) * N;
-    const float* y = Y + p * N;
+    const float* y = Y + (v_div ? (p / v_div) * E + ids[p] : p) * N;
     for (int c = l * 4; c < N; c += 64) {
       const float4 u = ld4(a + c), v = ld4(y + c);
       acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
@@ -1233,6 +1235,72 @@ __global__ __launch_bounds__(256) void gate_grad_kernel(const float* __restrict_
   if (p < P && l == 0) {
     const float gt = gate[p];
     dlogits[(p / k) * E + ids[p]] = acc * gt * (1.f - gt);
+  }
+}
+
+// Lists of the DISTINCT (row group, expert) combinations: group g = the fan pairs g*fan .. (one token's heads x slots in
+// SwitchHead), mask[g] = the set of experts its pairs chose.  Where every pair of a group reads the same input row
+// (moe_v: the token's row) or the products are summed over the group anyway (moe_out), the expert product is needed
+// once per distinct (group, expert): 12.9 of 16 at E 32, h 8, top-2.  The lists use "virtual pair" ids g*E + e, so the
+// grouped GEMMs run on them unchanged with a_div = E: input row g, output row g*E + e.
+__global__ __launch_bounds__(256) void expert_mask_kernel(const int64_t* __restrict__ ids, int64_t P, int fan,
+                                                          int groups_per_block, unsigned long long* __restrict__ mask, int64_t G) {
+  // a block takes groups_per_block whole groups = consecutive pairs: one coalesced id per thread, OR-ed into the group's
+  // mask in LDS
+  __shared__ unsigned long long m[256];
+  const int tid = threadIdx.x;
+  m[tid] = 0;
+  __syncthreads();
+  const int64_t g0 = (int64_t)blockIdx.x * groups_per_block;
+  const int span = groups_per_block * fan;
+  for (int i = tid; i < span; i += 256) {
+    const int64_t p = g0 * fan + i;
+    if (p < P) atomicOr(&m[i / fan], 1ull << (int)ids[p]);
+  }
+  __syncthreads();
+  if (tid < groups_per_block && g0 + tid < G) mask[g0 + tid] = m[tid];
+}
+
+// One workgroup per expert e.  Pass 1: offsets[e] = number of (group, expert') combinations with expert' < e, counted
+// straight from the masks (no counters, no atomics); pass 2: the expert's groups in ascending order (ballot ranks inside
+// a wave, wave totals through LDS).
+__global__ __launch_bounds__(1024) void expert_lists_kernel(const unsigned long long* __restrict__ mask, int64_t G, int E,
+                                                            int32_t* __restrict__ offsets, int32_t* __restrict__ perm) {
+  __shared__ int wtot[16];
+  __shared__ int wlow[16];
+  const int e = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long low = (1ull << e) - 1ull;
+  int below = 0, own = 0;
+  for (int64_t g = tid; g < G; g += 1024) {
+    const unsigned long long mk = mask[g];
+    below += __builtin_popcountll(mk & low);
+    own += (int)((mk >> e) & 1ull);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { below += __shfl_xor(below, o, 64); own += __shfl_xor(own, o, 64); }
+  if (lane == 0) { wlow[wave] = below; wtot[wave] = own; }
+  __syncthreads();
+  int base = 0, count = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) { base += wlow[w]; count += wtot[w]; }
+  if (tid == 0) {
+    offsets[e] = base;
+    if (e == E - 1) offsets[E] = base + count;
+  }
+  __syncthreads();
+  int running = base;
+  for (int64_t g0 = 0; g0 < G; g0 += 1024) {
+    const int64_t g = g0 + tid;
+    const bool has = g < G && ((mask[g] >> e) & 1ull);
+    const unsigned long long b = __ballot(has);
+    if (lane == 0) wtot[wave] = __builtin_popcountll(b);
+    __syncthreads();
+    int before = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { const int c = wtot[w]; total += c; if (w < wave) before += c; }
+    if (has) perm[running + before + __builtin_popcountll(b & ((1ull << lane) - 1ull))] = (int32_t)(g * E + e);
+    running += total;
+    __syncthreads();
   }
 }
 
@@ -1254,16 +1322,7 @@ static int wg_slots() {
 
 extern "C" int64_t amk_moe_route_ws_ints(int64_t U, int E, int k) { return ((U * k + 255) / 256) * E; }
 
-extern "C" int amk_moe_route(const float* logits, int64_t U, int E, int k,
-                             int64_t* ids, float* gate, int32_t* counts, int32_t* rank, int32_t* blockhist,
-                             int32_t* offsets, int32_t* perm, void* stream) {
-  AMK_CHECK_ARG(logits && ids && gate && counts && rank && blockhist && offsets && perm, "amk_moe_route: null pointer");
-  AMK_CHECK_SUPPORTED(E <= 1024, "amk_moe_route: at most 1024 experts");
-  AMK_CHECK_ARG(U > 0 && E > 0 && k > 0 && k <= E, "amk_moe_route: bad sizes U=%lld E=%d k=%d", (long long)U, E, k);
-  AMK_CHECK_SUPPORTED(k <= MAX_K, "amk_moe_route: sel_experts %d > %d", k, MAX_K);
-  const int64_t P = U * k;
-  AMK_CHECK_SUPPORTED(P < (1ll << 31), "amk_moe_route: too many routed pairs");
-  hipStream_t st = static_cast<hipStream_t>(stream);
+static void launch_topk(const float* logits, int64_t U, int E, int k, int64_t* ids, float* gate, hipStream_t st) {
   const dim3 tgrid((unsigned)((U + 127) / 128)), tblock(128);
   switch (k) {
     case 1: hipLaunchKernelGGL(route_topk_kernel<1>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
@@ -1275,6 +1334,28 @@ extern "C" int amk_moe_route(const float* logits, int64_t U, int E, int k,
     case 7: hipLaunchKernelGGL(route_topk_kernel<7>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
     default: hipLaunchKernelGGL(route_topk_kernel<8>, tgrid, tblock, 0, st, logits, U, E, ids, gate); break;
   }
+}
+
+extern "C" int amk_moe_topk(const float* logits, int64_t U, int E, int k, int64_t* ids, float* gate, void* stream) {
+  AMK_CHECK_ARG(logits && ids && gate, "amk_moe_topk: null pointer");
+  AMK_CHECK_ARG(U > 0 && E > 0 && k > 0 && k <= E, "amk_moe_topk: bad sizes U=%lld E=%d k=%d", (long long)U, E, k);
+  AMK_CHECK_SUPPORTED(k <= MAX_K && U * k < (1ll << 31), "amk_moe_topk: sel_experts %d > %d or too many pairs", k, MAX_K);
+  launch_topk(logits, U, E, k, ids, gate, static_cast<hipStream_t>(stream));
+  AMK_CHECK_LAUNCH("amk_moe_topk");
+  return AMK_OK;
+}
+
+extern "C" int amk_moe_route(const float* logits, int64_t U, int E, int k,
+                             int64_t* ids, float* gate, int32_t* counts, int32_t* rank, int32_t* blockhist,
+                             int32_t* offsets, int32_t* perm, void* stream) {
+  AMK_CHECK_ARG(logits && ids && gate && counts && rank && blockhist && offsets && perm, "amk_moe_route: null pointer");
+  AMK_CHECK_SUPPORTED(E <= 1024, "amk_moe_route: at most 1024 experts");
+  AMK_CHECK_ARG(U > 0 && E > 0 && k > 0 && k <= E, "amk_moe_route: bad sizes U=%lld E=%d k=%d", (long long)U, E, k);
+  AMK_CHECK_SUPPORTED(k <= MAX_K, "amk_moe_route: sel_experts %d > %d", k, MAX_K);
+  const int64_t P = U * k;
+  AMK_CHECK_SUPPORTED(P < (1ll << 31), "amk_moe_route: too many routed pairs");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  launch_topk(logits, U, E, k, ids, gate, st);
   const int nblk = (int)((P + ROUTE_BLOCK - 1) / ROUTE_BLOCK);
   hipLaunchKernelGGL(route_local_kernel, dim3(nblk), dim3(ROUTE_BLOCK), (size_t)(ROUTE_BLOCK / 64) * E * sizeof(int), st, ids, P, E, rank, blockhist);
   hipLaunchKernelGGL(route_scan_kernel, dim3(1), dim3(1024), 0, st, blockhist, nblk, E, counts, offsets);
@@ -1410,16 +1491,36 @@ extern "C" int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, co
   return AMK_OK;
 }
 
-extern "C" int amk_moe_combine(const float* Y, const int64_t* ids, const float* scale, int64_t G, int outer, int k,
-                               int N, float* out, void* stream) {
+extern "C" int amk_moe_combine_rows(const float* Y, const int64_t* ids, const float* scale, int64_t G, int outer, int k,
+                                    int N, int v_div, int E, float* out, void* stream) {
   AMK_CHECK_ARG(Y && ids && out, "amk_moe_combine: null pointer");
-  AMK_CHECK_ARG(G > 0 && outer > 0 && k > 0 && N > 0, "amk_moe_combine: non-positive size");
+  AMK_CHECK_ARG(G > 0 && outer > 0 && k > 0 && N > 0 && v_div >= 0 && (v_div == 0 || E > 0), "amk_moe_combine: non-positive size");
   AMK_CHECK_SUPPORTED(k <= MAX_K && N % 4 == 0 && a16(Y) && a16(out), "amk_moe_combine: k <= %d, N %% 4 == 0, aligned pointers", MAX_K);
   const int64_t n = G * (N / 4);
   AMK_CHECK_SUPPORTED((n + 255) / 256 < (1ll << 31), "amk_moe_combine: grid too large");
   hipLaunchKernelGGL(combine_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     Y, ids, scale, G, outer, k, N, out);
+                     Y, ids, scale, G, outer, k, N, v_div, E, out);
   AMK_CHECK_LAUNCH("amk_moe_combine");
+  return AMK_OK;
+}
+
+extern "C" int amk_moe_combine(const float* Y, const int64_t* ids, const float* scale, int64_t G, int outer, int k,
+                               int N, float* out, void* stream) {
+  return amk_moe_combine_rows(Y, ids, scale, G, outer, k, N, 0, 0, out, stream);
+}
+
+extern "C" int amk_moe_route_distinct(const int64_t* ids, int64_t G, int fan, int E, uint64_t* mask,
+                                      int32_t* offsets, int32_t* perm, void* stream) {
+  AMK_CHECK_ARG(ids && mask && offsets && perm, "amk_moe_route_distinct: null pointer");
+  AMK_CHECK_ARG(G > 0 && fan > 0 && E > 0, "amk_moe_route_distinct: non-positive size");
+  AMK_CHECK_SUPPORTED(E <= 64 && G * E < (1ll << 31) && fan <= 4096, "amk_moe_route_distinct: at most 64 experts, G*E < 2^31, fan <= 4096");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int gpb = fan >= 256 ? 1 : 256 / fan;   // groups per block of the mask kernel
+  hipLaunchKernelGGL(expert_mask_kernel, dim3((unsigned)((G + gpb - 1) / gpb)), dim3(256), 0, st, ids, G * fan, fan, gpb,
+                     reinterpret_cast<unsigned long long*>(mask), G);
+  hipLaunchKernelGGL(expert_lists_kernel, dim3((unsigned)E), dim3(1024), 0, st,
+                     reinterpret_cast<const unsigned long long*>(mask), G, E, offsets, perm);
+  AMK_CHECK_LAUNCH("amk_moe_route_distinct");
   return AMK_OK;
 }
 
@@ -1435,10 +1536,10 @@ extern "C" int amk_moe_expert_sums(const float* A, int64_t lda, int a_div, const
   return AMK_OK;
 }
 
-extern "C" int amk_moe_gate_grad(const float* d_out, const float* Y, const int64_t* ids, const float* gate,
-                                 int64_t P, int k, int E, int N, int g_div, float* dlogits, void* stream) {
+extern "C" int amk_moe_gate_grad_rows(const float* d_out, const float* Y, const int64_t* ids, const float* gate,
+                                      int64_t P, int k, int E, int N, int g_div, int v_div, float* dlogits, void* stream) {
   AMK_CHECK_ARG(d_out && Y && ids && gate && dlogits, "amk_moe_gate_grad: null pointer");
-  AMK_CHECK_ARG(P > 0 && k > 0 && E > 0 && N > 0 && g_div > 0, "amk_moe_gate_grad: non-positive size");
+  AMK_CHECK_ARG(P > 0 && k > 0 && E > 0 && N > 0 && g_div > 0 && v_div >= 0, "amk_moe_gate_grad: non-positive size");
   AMK_CHECK_SUPPORTED(N % 4 == 0 && a16(d_out) && a16(Y), "amk_moe_gate_grad: N %% 4 == 0, aligned pointers");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (hipMemsetAsync(dlogits, 0, (size_t)(P / k) * E * sizeof(float), st) != hipSuccess) {
@@ -1446,7 +1547,12 @@ extern "C" int amk_moe_gate_grad(const float* d_out, const float* Y, const int64
     return AMK_ELAUNCH;
   }
   hipLaunchKernelGGL(gate_grad_kernel, dim3((unsigned)((P + 15) / 16)), dim3(256), 0, st, d_out, Y, ids, gate, P, k, E, N,
-                     g_div, dlogits);
+                     g_div, v_div, dlogits);
   AMK_CHECK_LAUNCH("amk_moe_gate_grad");
   return AMK_OK;
+}
+
+extern "C" int amk_moe_gate_grad(const float* d_out, const float* Y, const int64_t* ids, const float* gate,
+                                 int64_t P, int k, int E, int N, int g_div, float* dlogits, void* stream) {
+  return amk_moe_gate_grad_rows(d_out, Y, ids, gate, P, k, E, N, g_div, 0, dlogits, stream);
 }

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 133 /* 0.3.3: amk_moe_expert_sums; 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
+#define AMK_VERSION 134 /* 0.3.4: amk_moe_route_distinct, _rows forms of combine / gate_grad; 0.3.3: amk_moe_expert_sums; 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
 
 enum {
   AMK_OK = 0,
@@ -280,6 +280,28 @@ int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, const float* 
  * head sum of switchhead_attention.py:115.  scale (G*outer*k) or NULL (moe_out is un-weighted). */
 int amk_moe_combine(const float* Y, const int64_t* ids, const float* scale, int64_t G, int outer, int k,
                     int N, float* out, void* stream);
+
+/* The selection alone: ids (U,k) = top-k expert indices of every logits row (descending value, lowest index on ties, as
+ * torch.topk), gate (U,k) = sigmoid of the selected logits -- the first stage of amk_moe_route, for callers that build
+ * their own lists (amk_moe_route_distinct). */
+int amk_moe_topk(const float* logits, int64_t U, int E, int k, int64_t* ids, float* gate, void* stream);
+
+/* Lists of the DISTINCT (row group, expert) combinations of a routing: group g = pairs g*fan .. g*fan+fan-1 (in
+ * SwitchHead one token's heads x slots).  Where all pairs of a group read the same input row (moe_v,
+ * switchhead_attention.py:58-73: the token's row for every head) or their products are summed over the group anyway
+ * (moe_out, :75-88,115), an expert's product is needed once per distinct (group, expert) -- 12.9 instead of 16 per
+ * token at E 32, h 8, top-2.  offsets (E+1) / perm (up to G*min(fan,E) entries) list "virtual pairs" g*E + e by expert,
+ * groups ascending; the amk_grouped_gemm_* entry points run on them unchanged with P = G*E, a_div = E (input row g,
+ * output row g*E + e).  mask (G) is a workspace.  E <= 64, fan <= 4096. */
+int amk_moe_route_distinct(const int64_t* ids, int64_t G, int fan, int E, uint64_t* mask,
+                           int32_t* offsets, int32_t* perm, void* stream);
+
+/* amk_moe_combine / amk_moe_gate_grad reading such per-(group, expert) rows: pair p reads Y row
+ * (p / v_div) * E + ids[p]  (v_div = pairs per group; v_div == 0: row p, the plain entry points). */
+int amk_moe_combine_rows(const float* Y, const int64_t* ids, const float* scale, int64_t G, int outer, int k,
+                         int N, int v_div, int E, float* out, void* stream);
+int amk_moe_gate_grad_rows(const float* d_out, const float* Y, const int64_t* ids, const float* gate,
+                           int64_t P, int k, int E, int N, int g_div, int v_div, float* dlogits, void* stream);
 
 /* Z[g, e, :] = sum over the fan pairs of row g (pairs g*fan .. g*fan+fan-1) that chose expert e = ids[p] of
  * scale[p] * A[p / a_div, :]  (d floats at stride lda; scale (G*fan) or NULL).  Z (G, E*d) is fully overwritten, in a

@@ -214,3 +214,42 @@ def test_expert_sums(device, G, fan, a_div, E, d, weighted):
     src = A.double()[p // a_div] * (scale.double()[:, None] if weighted else 1.0)
     ref = torch.zeros(G * E, d, dtype=torch.float64, device=device).index_add_(0, (p // fan) * E + ids, src)
     assert_close(Z.view(G * E, d), ref.float(), 2e-6, "expert sums")
+
+
+@pytest.mark.parametrize("G,fan,E", [(4160, 16, 32), (37, 6, 64), (1, 1, 1), (1500, 300, 7), (2049, 2, 5)])
+def test_distinct_lists(device, G, fan, E):
+    """amk_moe_route_distinct: per expert the groups (ascending) in which some pair chose it, as virtual pairs g*E + e."""
+    from amk import ops
+
+    g = torch.Generator().manual_seed(G + fan + E)
+    ids = torch.randint(0, E, (G * fan,), generator=g)
+    offsets, perm = ops._route_distinct(ids.to(device), G, fan, E)
+    offsets, perm = offsets.cpu().tolist(), perm.cpu().tolist()
+    present = torch.zeros(G, E, dtype=torch.bool)
+    present[torch.arange(G * fan) // fan, ids] = True
+    assert offsets[0] == 0 and offsets[E] == int(present.sum())
+    for e in range(E):
+        want = [int(t) * E + e for t in torch.nonzero(present[:, e]).flatten()]
+        assert perm[offsets[e]:offsets[e + 1]] == want, e
+
+
+def test_combine_rows_reads_per_group_expert_rows(device):
+    """amk_moe_combine_rows with v_div: pair p reads row (p / v_div) * E + ids[p]."""
+    import ctypes
+
+    from amk import lib as amk_lib
+    from amk import ops
+
+    G, H, k, E, N = 9, 4, 2, 8, 12
+    U, fan = G * H, H * k
+    g = torch.Generator().manual_seed(5)
+    V = torch.randn(G * E, N, generator=g).to(device)
+    logits = torch.randn(U, E, generator=g).to(device)
+    ids, gate = ops._topk(logits, k)
+    out = torch.empty(U, N, device=device)
+    L = amk_lib.load()
+    amk_lib.check(L.amk_moe_combine_rows(ops._ptr(V), ops._ptr(ids), ops._ptr(gate), U, 1, k, N, fan, E, ops._ptr(out),
+                                         ops._stream()), "amk_moe_combine_rows")
+    tok = (torch.arange(U * k, device=device) // fan).view(U, k)
+    ref = (V.double()[tok * E + ids] * gate.double()[..., None]).sum(1)
+    assert_close(out, ref.float(), 1e-6, "combine rows")

@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--events", action="store_true", help="HIP events around the routed-expert launches: per-launch table")
     ap.add_argument("--no-tune", action="store_true", help="library GEMMs without TunableOp (keeps its trial kernels out of a profile)")
     a = ap.parse_args()
     from amk import tuning
@@ -46,6 +47,17 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     print(f"ViTMoE batch {a.batch}: {dt*1e3:.2f} ms per step (host enqueue {t_host/a.steps*1e3:.2f} ms)")
+    if a.events:
+        from amk import ops
+
+        ops.KERNEL_EVENTS = {}
+        for _ in range(a.steps):
+            step()
+        torch.cuda.synchronize()
+        ev = ops.kernel_event_summary(ops.KERNEL_EVENTS)
+        ops.KERNEL_EVENTS = None
+        for name, (n, ms) in sorted(ev.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+            print(f"  {name:60s} {n / a.steps:5.1f} per step  {ms * 1e3:8.1f} us  {ms * n / a.steps:7.3f} ms per step")
 
 
 if __name__ == "__main__":
