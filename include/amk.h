@@ -312,8 +312,8 @@ int amk_moe_gate_grad_rows(const float* d_out, const float* Y, const int64_t* id
 int amk_moe_expert_sums(const float* A, int64_t lda, int a_div, const int64_t* ids, const float* scale,
                         int64_t G, int fan, int E, int d, float* Z, void* stream);
 
-/* Gradient of the gate logits through sigmoid(topk): dlogits (P/k, E) is zeroed, then
- * dlogits[p/k, ids[p]] = gate[p]*(1-gate[p]) * <d_out[p / g_div, :], Y[p, :]>. */
+/* Gradient of the gate logits through sigmoid(topk): dlogits (P/k, E) fully overwritten,
+ * dlogits[p/k, ids[p]] = gate[p]*(1-gate[p]) * <d_out[p / g_div, :], Y[p, :]>, zero elsewhere. */
 int amk_moe_gate_grad(const float* d_out, const float* Y, const int64_t* ids, const float* gate,
                       int64_t P, int k, int E, int N, int g_div, float* dlogits, void* stream);
 
