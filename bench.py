@@ -250,7 +250,8 @@ def agent_block(dev, iters, batch=64):
 def vitmoe_block(dev, batch=64, steps=3):
     """Secondary, informational: BASELINE.json configs[3] (ViTMoE dim 1024, patch 32, depth 6, 32 experts top-2,
     SwitchHead h 8) forward + backward at batch 64, with HIP events around every routed-expert launch.
-    Grouped expert GEMMs are credited 2*P*N*K FLOP (P routed pairs), against the f32 MFMA peak."""
+    Grouped expert GEMMs are credited 2*P*N*K FLOP (P routed pairs: the reference's work, also where a launch marked
+    "(distinct rows)" forms an expert's product once per distinct (token, expert)), against the f32 MFMA peak."""
     import re
 
     from amk import ops as amk_ops
