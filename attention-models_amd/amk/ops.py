@@ -1308,10 +1308,19 @@ class _LinearX6(torch.autograd.Function):
 DENSE_MODE = os.environ.get("AMK_DENSE", "auto")
 
 
+# `auto` keeps the own kernels to contractions of at most this many input features.  They were built for (and win or tie
+# on) the ViT-VQGAN layers, K = 256 / 512: short contractions, where the vendor kernels are epilogue-dominated and the
+# persistent walk hides the epilogue.  At K >= 1024 -- the ViT classifier of configs[1], the ViTMoE projections -- the tuned
+# vendor kernels are 10-45 % faster (tools/kbench_vit.py: 7.5 against 9.8 ms per step at batch 64; tools/scratch/dense_z_probe.py).
+DENSE_AUTO_MAX_K = int(os.environ.get("AMK_DENSE_MAX_K", "512"))
+
+
 def _dense_ok(x, *weights):
     if DENSE_MODE == "lib" or torch.is_autocast_enabled() or not x.is_cuda or x.dtype != torch.float32 or x.numel() == 0:
         return False
     if x.shape[-1] % 4 or x.shape[-1] < 128:
+        return False
+    if DENSE_MODE == "auto" and x.shape[-1] > DENSE_AUTO_MAX_K:
         return False
     return all(w.dtype == torch.float32 and w.shape[0] % 4 == 0 and w.shape[0] >= 128 and w.is_contiguous() for w in weights)
 

@@ -1,7 +1,7 @@
 """BASELINE.json configs[1]: ViT classifier (dim 1024, patch 32, 16 heads, depth 6 -> 65 tokens) training
 step (forward, cross-entropy, backward, AdamW) on synthetic images.
 
-    python tools/kbench_vit.py
+    python tools/kbench_vit.py [batch ...]
 """
 import os
 import sys
@@ -22,7 +22,7 @@ model = ViT(dim=1024, image_size=256, patch_size=32, n_heads=16, d_head=64, dept
             num_classes=1000).to(dev)
 opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=True)
 print(f"ViT parameters: {sum(p.numel() for p in model.parameters())/1e6:.1f} M")
-for B in (2, 64, 256):
+for B in ([int(b) for b in sys.argv[1:]] or (2, 64, 256)):
     imgs = torch.randn(B, 3, 256, 256, device=dev)
     labels = torch.randint(0, 1000, (B,), device=dev)
 
