@@ -159,7 +159,7 @@ class AgentAttention(nn.Module):
                 f"AgentAttention needs num_heads == int(agent_num ** 0.5) (got {num_heads} vs {self.pool_size}): "
                 "the reference's einsum fails otherwise (models/agent_attention.py:56-60)")
         inner = num_heads * dim_head
-        self.qkv = nn.Linear(dim, 3 * inner, bias=False)
+        self.qkv = Linear(dim, 3 * inner, bias=False)   # layers.Linear: nn.Linear's parameters, ops.linear's kernels
         self.scale = dim_head ** -0.5
         self.W_o = Linear(inner, dim)
         self.dropout_p = float(dropout)
