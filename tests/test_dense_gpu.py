@@ -170,3 +170,18 @@ def test_refuses_cpu_and_bad_shapes(device):
         dense.gemm_nt(torch.randn(4, 4), torch.randn(4, 4))
     with pytest.raises(RuntimeError, match="multiples of 4"):
         dense.gemm_nt(torch.randn(4, 6, device=device), torch.randn(4, 6, device=device))
+
+
+def test_auto_mode_keeps_wide_contractions_on_the_library(device, monkeypatch):
+    """AMK_DENSE=auto: the own kernels take inputs of at most ops.DENSE_AUTO_MAX_K features (the ViT-VQGAN layers); the
+    ViT classifier's K = 1024 layers stay on the vendor kernels, which are faster there."""
+    from amk import ops
+
+    monkeypatch.setattr(ops, "DENSE_MODE", "auto")
+    w = torch.empty(1024, 256, device=device)
+    assert ops._dense_ok(torch.empty(64, 256, device=device), w)
+    assert not ops._dense_ok(torch.empty(64, 1024, device=device), torch.empty(1024, 1024, device=device))
+    monkeypatch.setattr(ops, "DENSE_MODE", "amk")
+    assert ops._dense_ok(torch.empty(64, 1024, device=device), torch.empty(1024, 1024, device=device))
+    monkeypatch.setattr(ops, "DENSE_MODE", "lib")
+    assert not ops._dense_ok(torch.empty(64, 256, device=device), w)
