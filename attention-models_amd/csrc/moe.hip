@@ -222,6 +222,7 @@ struct GemmParams {
   int64_t b_bytes, s_bytes;  // wgrad: sizes of the X and scale buffers
   int a_shift, b_shift;  // log2 of a_div / b_div when they are powers of two, else -1
   int y_div;             // wide nt / nn: > 0 = accumulate mode, pair p ADDS into output row p / y_div (f32 atomics)
+  int rsplit;            // wide wgrad: 2 = an expert's pairs cut in two, both halves ADD into a zeroed dW (0 + a + b: order-free)
 };
 
 // Locate this workgroup's unit = (expert, output tile, 64-pair row tile).  The grid is 1-D over the units in
@@ -962,10 +963,20 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g
   __shared__ float tab_s[4][32];
   constexpr unsigned PAST = 0x80000000u, COL_PAST = 0x7FFF0000u;  // as in nt_panel_body
   const int ntn = (g.N + WG_ - 1) / WG_, ntk = g.ncol;  // tiles along n, kk
-  const int u = xcd_remap(blockIdx.x, gridDim.x);
+  const int u2 = xcd_remap(blockIdx.x, gridDim.x);
+  // rsplit 2: neighbouring workgroups take the two halves of a tile's pairs.  With few tiles -- SwitchHead's 64-wide experts
+  // make E x 8 = 256, one workgroup and one wave per SIMD on every CU -- nothing covers a workgroup's waits (MFMA pipe busy
+  // 0.43-0.46, profiles/r03_vitmoe_pmc_digest.txt); two half-length workgroups per CU cover each other's.
+  const int part = g.rsplit == 2 ? (u2 & 1) : 0;
+  const int u = g.rsplit == 2 ? (u2 >> 1) : u2;
   const int e = __builtin_amdgcn_readfirstlane(u / (ntn * ntk)), rem = u - e * ntn * ntk;
   const int n0 = (rem / ntk) * WG_, c0 = (rem % ntk) * WX_;
-  const int beg = g.offsets[e], cnt = g.offsets[e + 1] - beg;
+  int beg = g.offsets[e], cnt = g.offsets[e + 1] - beg;
+  if (g.rsplit == 2) {
+    const int first = ((cnt + 63) >> 6) << 5;   // the first half, in whole 32-pair steps
+    if (part) { beg += min(first, cnt); cnt = max(cnt - first, 0); }
+    else cnt = min(cnt, first);
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;  // wm: n half, wn: kk half
   const int nstep = (cnt + 31) >> 5;
@@ -1127,8 +1138,11 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const float v = acc[i][j][r];  // (a copy: bit_cast of the vector-element lvalue itself reads element 0)
-        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d_rsrc,
-                                              (int)(nbase + (unsigned)(acc_row(r, 0) * row_bytes) + coff), 0, 0);
+        if (g.rsplit == 2)
+          __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, d_rsrc, (int)(nbase + (unsigned)(acc_row(r, 0) * row_bytes) + coff), 0, 0);
+        else
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), d_rsrc,
+                                                (int)(nbase + (unsigned)(acc_row(r, 0) * row_bytes) + coff), 0, 0);
       }
     }
   }
@@ -1137,7 +1151,10 @@ __global__ __launch_bounds__(256, 2) void grouped_wgrad_wide_kernel(GemmParams g
     for (int i = 0; i < TNB; ++i) {
       const float t = bsum[i] + __shfl_xor(bsum[i], 32, 64);
       const int n = n0 + 32 * TNB * wm + 32 * i + ln;
-      if (hf == 0 && n < g.N) g.dbias[(int64_t)e * g.N + n] = t;
+      if (hf == 0 && n < g.N) {
+        if (g.rsplit == 2) atomicAdd(&g.dbias[(int64_t)e * g.N + n], t);
+        else g.dbias[(int64_t)e * g.N + n] = t;
+      }
     }
   }
 }
@@ -1495,10 +1512,23 @@ extern "C" int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, co
     // tile 128 x 128; 64 x 128 / 128 x 64 for SwitchHead's (64 x D) / (D x 64) experts
     const int tn = N >= 128 ? 128 : 64, tk = Kd >= 128 ? 128 : 64;
     g.ncol = (Kd + tk - 1) / tk;
-    const int64_t nwg = (int64_t)E * ((N + tn - 1) / tn) * g.ncol;
-    AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_grouped_gemm_wgrad: grid too large");
-    const dim3 grid((unsigned)nwg), block(256);
+    int64_t nwg = (int64_t)E * ((N + tn - 1) / tn) * g.ncol;
+    AMK_CHECK_SUPPORTED(nwg < (1ll << 30), "amk_grouped_gemm_wgrad: grid too large");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // fewer tiles than workgroup slots and long experts: the pairs of a tile in two halves that add into a zeroed dW
+    // (AMK_MOE_WGRAD_SPLIT=0: never)
+    static const bool split_ok = !(getenv("AMK_MOE_WGRAD_SPLIT") && atoi(getenv("AMK_MOE_WGRAD_SPLIT")) == 0);
+    g.rsplit = 1;
+    if (split_ok && 2 * nwg <= wg_slots() && P / E >= 256) {
+      g.rsplit = 2;
+      nwg *= 2;
+      if (hipMemsetAsync(dW, 0, (size_t)E * N * Kd * sizeof(float), st) != hipSuccess ||
+          (dbias && hipMemsetAsync(dbias, 0, (size_t)E * N * sizeof(float), st) != hipSuccess)) {
+        amk_set_error("amk_grouped_gemm_wgrad: hipMemsetAsync failed");
+        return AMK_ELAUNCH;
+      }
+    }
+    const dim3 grid((unsigned)nwg), block(256);
 #define AMK_WGRAD(S, TN_, TK_) hipLaunchKernelGGL((grouped_wgrad_wide_kernel<S, TN_, TK_>), grid, block, 0, st, g)
     if (tn == 128 && tk == 128) { if (scale) AMK_WGRAD(true, 2, 2); else AMK_WGRAD(false, 2, 2); }
     else if (tn == 64) { if (scale) AMK_WGRAD(true, 1, 2); else AMK_WGRAD(false, 1, 2); }

@@ -270,7 +270,9 @@ int amk_grouped_gemm_nn_acc(const float* A, int64_t lda, int a_div, const float*
                             float* Y, int y_div, void* stream);
 
 /* dW[e] = sum_{p in e} scale[p] * G[p / g_div, :]^T (x) X[p / x_div, :]   (E,N,Kd), fully
- * overwritten; dbias[e] = sum_{p in e} scale[p] * G[p / g_div, :] (E,N) or NULL. */
+ * overwritten; dbias[e] = sum_{p in e} scale[p] * G[p / g_div, :] (E,N) or NULL.  (With few output tiles and long
+ * experts the entry zeroes dW and two workgroups per tile add their halves of the pairs: 0 + a + b, the same bits in
+ * either order.) */
 int amk_grouped_gemm_wgrad(const float* G, int64_t ldg, int g_div, const float* X, int64_t ldx, int x_div,
                            const float* scale, const int32_t* offsets, const int32_t* perm,
                            int64_t P, int E, int N, int Kd, float* dW, float* dbias, void* stream);
