@@ -21,6 +21,8 @@ CASES = [
     (520, 2, 8, 1024, 64, 1, 1, 0),     # SwitchHead output experts: K = 64
     (9, 1, 3, 128, 96, 1, 1, 0),        # depth that is a multiple of 32 only
     (2000, 2, 2, 128, 128, 2, 2, 0),    # many rows per expert (tiles of four blocks, several rounds)
+    (1500, 2, 4, 64, 256, 2, 2, 1),     # few output tiles, long experts: the weight gradient's two-workgroup form, one expert empty
+    (5000, 1, 16, 256, 64, 1, 1, -1),   # the same with skewed routing: experts of a handful of pairs next to long ones
 ]
 
 
@@ -29,8 +31,10 @@ def _route(R, k, E, empty, dev, seed):
 
     g = torch.Generator().manual_seed(seed)
     logits = torch.randn(R, E, generator=g)
-    if empty:
+    if empty > 0:
         logits[:, :empty] = -1e4  # never chosen
+    elif empty < 0:
+        logits += torch.linspace(-7.0, 3.0, E)  # skewed: the first experts get a few pairs, the last ones most
     return ops.moe_route(logits.to(dev), k)
 
 
