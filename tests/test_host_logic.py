@@ -177,3 +177,19 @@ def test_checkpoint_format_round_trip(tmp_path):
         assert torch.equal(a, b), n
     tr2 = VQGANTrainStep(ViTVQGAN(vit, cb), NLayerDiscriminator(3, 8, 3))
     assert tr2.resume_from_checkpoint(path) == {"model": {"name": "vitvqgan"}} and tr2.global_step == 37
+
+
+def test_switchhead_form_rule(monkeypatch):
+    """ops._moe_dense_z: the dense-sum / distinct-row forms apply where a row sums at least E/2 pairs into a wide output
+    (SwitchHead at the ViTMoE layer: 16 pairs, 32 experts, 1024 wide, 64 per pair) and not to the top-2 MoE layer."""
+    from amk import ops
+
+    monkeypatch.setattr(ops, "MOE_DENSE_Z", True)
+    assert ops._moe_dense_z(1024, 64, 16, 32)
+    assert ops._moe_dense_z(512, 64, 4, 5)
+    assert not ops._moe_dense_z(1024, 1024, 2, 32)      # MoELayer: two pairs per row
+    assert not ops._moe_dense_z(1024, 64, 15, 32)       # fewer than E/2 pairs
+    assert not ops._moe_dense_z(128, 64, 16, 32)        # narrow output
+    assert not ops._moe_dense_z(256, 128, 16, 32)       # output less than 4x the contraction
+    monkeypatch.setattr(ops, "MOE_DENSE_Z", False)
+    assert not ops._moe_dense_z(1024, 64, 16, 32)
