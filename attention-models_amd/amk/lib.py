@@ -59,6 +59,7 @@ SIGNATURES = {
     "amk_agent_ws_floats": (_L, [_I, _I, _I, _I, _I]),
     "amk_agent_attn_fwd": (_I, [_P] * 10 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_agent_attn_bwd": (_I, [_P] * 14 + [_I] * 5 + [_L] * 21 + [_F, _P]),
+    "amk_agent_conv_grad_reduce": (_I, [_P, _P, _L, _I, _P, _P, _P]),
     "amk_rowsum_num_partials": (_I, [_L]),
     "amk_add_layernorm_fwd": (_I, [_P, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),
     "amk_add_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),

@@ -916,8 +916,10 @@ class _AgentAttn(torch.autograd.Function):
                                   B, H, T, D, P, *_strides4(q), *_strides4(k), *_strides4(v), *_strides4(d_o),
                                   *_strides4(dq), *_strides4(dk), *_strides4(dv), float(scale), _stream())
         _lib.check(rc, "amk_agent_attn_bwd")
-        dconv_w = dw_part.sum(0).t().reshape(D, 1, 3, 3)
-        dconv_b = db_part.sum(0)
+        dconv_w = torch.empty((D, 1, 3, 3), device=dev, dtype=torch.float32)
+        dconv_b = torch.empty((D,), device=dev, dtype=torch.float32)
+        _lib.check(L.amk_agent_conv_grad_reduce(_ptr(dw_part), _ptr(db_part), cells, D, _ptr(dconv_w), _ptr(dconv_b), _stream()),
+                   "amk_agent_conv_grad_reduce")
         return dqkv2, dconv_w, dconv_b, None, None, None, None
 
 

@@ -1142,6 +1142,45 @@ extern "C" int amk_agent_attn_bwd(const float* q, const float* k, const float* v
   return AMK_OK;
 }
 
+// dconvw[c][a*3+b] = sum over the rows of dconvw_part[row][a*3+b][c]; dconvb[c] = sum of dconvb_part[row][c]: one launch,
+// a fixed order, the weight gradient written in the parameter's own (d, 1, 3, 3) layout -- instead of two library
+// reductions and a transposing copy.  A workgroup takes one tap (or the bias) and 16 channels: 64 strided row walks of
+// float4s in flight side by side, folded through LDS in a fixed order.
+__global__ __launch_bounds__(256) void agent_conv_reduce_kernel(const float* __restrict__ wpart, const float* __restrict__ bpart,
+                                                                int64_t rows, float* __restrict__ dconvw, float* __restrict__ dconvb) {
+  __shared__ float red[64][17];
+  const int r = blockIdx.x;                       // 0..8: weight tap, 9: bias
+  const int c4i = threadIdx.x & 3, part = threadIdx.x >> 2, c0 = blockIdx.y * 16;
+  const float* src = (r < 9 ? wpart + (int64_t)r * amk_agent::D : bpart) + c0 + c4i * 4;
+  const int64_t stride = r < 9 ? 9 * amk_agent::D : amk_agent::D;
+  float4 acc = amk_agent::f4(0.f);
+  for (int64_t i = part; i < rows; i += 64) {
+    const float4 v = amk_agent::ld4(src + i * stride);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  red[part][c4i * 4 + 0] = acc.x; red[part][c4i * 4 + 1] = acc.y; red[part][c4i * 4 + 2] = acc.z; red[part][c4i * 4 + 3] = acc.w;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+    for (int j = 0; j < 64; ++j) t += red[j][threadIdx.x];
+    const int c = c0 + threadIdx.x;
+    if (r < 9) dconvw[c * 9 + r] = t;
+    else dconvb[c] = t;
+  }
+}
+
+extern "C" int amk_agent_conv_grad_reduce(const float* dconvw_part, const float* dconvb_part, int64_t rows, int Dh,
+                                          float* dconvw, float* dconvb, void* stream) {
+  AMK_CHECK_ARG(dconvw_part && dconvb_part && dconvw && dconvb && rows > 0, "amk_agent_conv_grad_reduce: null pointer or no rows");
+  AMK_CHECK_SUPPORTED(Dh == amk_agent::D, "amk_agent_conv_grad_reduce: head dim %d not supported (built for %d)", Dh, amk_agent::D);
+  AMK_CHECK_ARG((reinterpret_cast<uintptr_t>(dconvw_part) & 15) == 0 && (reinterpret_cast<uintptr_t>(dconvb_part) & 15) == 0,
+                "amk_agent_conv_grad_reduce: partials must be 16-byte aligned");
+  hipLaunchKernelGGL(agent_conv_reduce_kernel, dim3(10, amk_agent::D / 16), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     dconvw_part, dconvb_part, rows, dconvw, dconvb);
+  AMK_CHECK_LAUNCH("amk_agent_conv_grad_reduce");
+  return AMK_OK;
+}
+
 // diagnostic (not part of the ABI): resident workgroups per CU the runtime computes for the chunk kernels
 extern "C" int amk_debug_agent_occupancy(int which) {
   int n = -1;

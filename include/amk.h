@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 134 /* 0.3.4: amk_moe_route_distinct, _rows forms of combine / gate_grad; 0.3.3: amk_moe_expert_sums; 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
+#define AMK_VERSION 135 /* 0.3.5: amk_agent_conv_grad_reduce; 0.3.4: amk_moe_route_distinct, _rows forms of combine / gate_grad; 0.3.3: amk_moe_expert_sums; 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
 
 enum {
   AMK_OK = 0,
@@ -359,6 +359,11 @@ int amk_agent_attn_bwd(const float* q, const float* k, const float* v, const flo
                        int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t do_sb, int64_t do_st, int64_t do_sh,
                        int64_t dq_sb, int64_t dq_st, int64_t dq_sh, int64_t dk_sb, int64_t dk_st, int64_t dk_sh,
                        int64_t dv_sb, int64_t dv_st, int64_t dv_sh, float scale, void* stream);
+
+/* The sums over the first axis of amk_agent_attn_bwd's partials, in a fixed order, in one launch: dconvw (D, 1, 3, 3)
+ * = the depthwise convolution's weight gradient in the parameter's layout (agent_attention.py:41-45), dconvb (D). */
+int amk_agent_conv_grad_reduce(const float* dconvw_part, const float* dconvb_part, int64_t rows, int D,
+                               float* dconvw, float* dconvb, void* stream);
 
 /* --------------------------------------------------------------------------
  * Residual-add + LayerNorm and the bias-gradient column sum (the
