@@ -231,17 +231,18 @@ struct GemmParams {
 // the surplus workgroups leave) so that adjacent units run on one XCD, behind one L2: as a 2-D grid the five
 // row tiles of a panel were dealt to five XCDs and each fetched the panel from HBM (PMC: 693 MB read per
 // forward for 185 MB of operands).
+template <int TR = 64>   // pairs per tile
 __device__ __forceinline__ bool find_unit(const int32_t* offsets, int E, int ncol, int bid, int& e, int& m0, int& cnt, int& ct) {
   int T = 0;
-  for (int j = 0; j < E; ++j) T += (offsets[j + 1] - offsets[j] + 63) >> 6;
+  for (int j = 0; j < E; ++j) T += (offsets[j + 1] - offsets[j] + TR - 1) / TR;
   const int total = T * ncol;
   if (bid >= total) return false;
   int u = xcd_remap(bid, total);
   for (int j = 0; j < E; ++j) {
     const int c = offsets[j + 1] - offsets[j];
-    const int nt = (c + 63) >> 6;
+    const int nt = (c + TR - 1) / TR;
     const int blk = nt * ncol;
-    if (u < blk) { e = j; ct = u / nt; m0 = (u - ct * nt) * 64; cnt = c; return true; }
+    if (u < blk) { e = j; ct = u / nt; m0 = (u - ct * nt) * TR; cnt = c; return true; }
     u -= blk;
   }
   return false;
@@ -252,20 +253,25 @@ __device__ __forceinline__ bool find_unit(const int32_t* offsets, int E, int nco
 // 64-wide outputs of SwitchHead's V experts).
 
 // Y[p, n] = sum_kk A[arow(p), kk] * W[e, n, kk] (+ bias[e, n])        tile: 64 pairs x 64*NB outputs
-template <int NB>
+// SHORT (NB 1): 32 pairs x 64 outputs; the waves are 2 (output halves) x 2 (halves of every k-slab) and the two k-halves
+// are added through LDS at the end, in a fixed order.  For launches of a few workgroups per CU -- SwitchHead's 64-wide
+// experts at batch 64 are 840 tiles of 64 pairs on 256 CUs, all resident at once, and the kernel lasts as long as the CUs
+// that drew four of them -- twice as many, half as long workgroups even the CUs out and cover each other's waits.
+template <int NB, bool SHORT = false>
 __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
-  constexpr int LS = 36, BN = 64 * NB;
-  __shared__ __attribute__((aligned(16))) float smem[(64 + BN) * LS];
-  __shared__ int prow[64];
+  static_assert(!SHORT || NB == 1, "the short tile serves the 64-wide outputs");
+  constexpr int LS = 36, BN = 64 * NB, TR = SHORT ? 32 : 64, AJ = TR / 32;
+  __shared__ __attribute__((aligned(16))) float smem[(TR + BN) * LS];
+  __shared__ int prow[TR];
   float* As = smem;
-  float* Ws = smem + 64 * LS;
+  float* Ws = smem + TR * LS;
   int e, m0, cnt, ct;
-  if (!find_unit(g.offsets, g.E, g.ncol, blockIdx.x, e, m0, cnt, ct)) return;
+  if (!find_unit<TR>(g.offsets, g.E, g.ncol, blockIdx.x, e, m0, cnt, ct)) return;
   const int n0 = ct * BN;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = SHORT ? 0 : wave >> 1, wn = wave & 1, wk = SHORT ? wave >> 1 : 0;
   const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
-  if (tid < 64) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
+  if (tid < TR) prow[tid] = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
   __syncthreads();
   const float* We = g.W + (int64_t)e * g.N * g.Kd;
 
@@ -277,20 +283,20 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
   constexpr unsigned PASTO = 0x80000000u;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7ffffffe, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, 0x7ffffffe, 0x00020000);
-  unsigned aoffs[2], woffs[2 * NB];   // (the host checks that A and one expert's weights span < 2 GiB)
+  unsigned aoffs[AJ], woffs[2 * NB];   // (the host checks that A and one expert's weights span < 2 GiB)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < AJ; ++j) {
     const int pp = prow[sr + 32 * j];
     aoffs[j] = pp >= 0 ? (unsigned)(((int64_t)(pp / g.a_div) * g.lda + sc) * 4) : PASTO;
   }
 #pragma unroll
   for (int j = 0; j < 2 * NB; ++j)
     woffs[j] = (n0 + sr + 32 * j < g.N) ? (unsigned)(((int64_t)(n0 + sr + 32 * j) * g.Kd + sc) * 4) : PASTO;
-  float4 ast[2], wst[2 * NB];
+  float4 ast[AJ], wst[2 * NB];
   auto prefetch = [&](int k0) {   // (k0 past the contraction: every piece reads zeros)
     const bool kin = k0 + sc < g.Kd;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < AJ; ++j)
       ast[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)((kin && aoffs[j] != PASTO) ? aoffs[j] + 4u * k0 : PASTO), 0, 0));
 #pragma unroll
     for (int j = 0; j < 2 * NB; ++j)
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) st4(&As[(sr + 32 * j) * LS + sc], ast[j]);
+    for (int j = 0; j < AJ; ++j) st4(&As[(sr + 32 * j) * LS + sc], ast[j]);
 #pragma unroll
     for (int j = 0; j < 2 * NB; ++j) st4(&Ws[(sr + 32 * j) * LS + sc], wst[j]);
   };
@@ -312,10 +318,10 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
     __syncthreads();
     prefetch(k0 + 32);
     if (!rows_here) continue;  // a tail tile with at most 32 pairs: this wave's row half is empty
-    const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
-    const float* wr = &Ws[(32 * NB * wn + ln) * LS + 16 * hf];
+    const float* ar = &As[(32 * wm + ln) * LS + 16 * hf + (SHORT ? 8 * wk : 0)];
+    const float* wr = &Ws[(32 * NB * wn + ln) * LS + 16 * hf + (SHORT ? 8 * wk : 0)];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
+    for (int s4 = 0; s4 < (SHORT ? 2 : 4); ++s4) {
       const float4 a = ld4(ar + 4 * s4);
       float4 b[NB];
 #pragma unroll
@@ -326,6 +332,18 @@ __global__ __launch_bounds__(256, 2) void grouped_nt_kernel(GemmParams g) {
         for (int j = 0; j < NB; ++j) acc[j] = mfma32(f4(a, x), f4(b[j], x), acc[j]);
       }
     }
+  }
+  if (SHORT) {  // acc(k-half 0) + acc(k-half 1), through the staging space
+    __syncthreads();
+    float* red = smem + wn * (16 * 64);
+    if (wk == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (wk == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] += red[r * 64 + lane];
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -744,21 +762,23 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_wide_kernel(GemmParams g) {
 }
 
 // Y[p, kk] = scale[p] * sum_n A[arow(p), n] * W[e, n, kk]              tile: 64 pairs x 64*NB outputs
-template <int NB>
+// SHORT (NB 1): 32 pairs x 64 outputs, the waves as 2 output halves x 2 halves of every slab (see grouped_nt_kernel)
+template <int NB, bool SHORT = false>
 __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
-  constexpr int LS = 36, BC = 64 * NB, WS = BC + 4;
+  static_assert(!SHORT || NB == 1, "the short tile serves the 64-wide outputs");
+  constexpr int LS = 36, BC = 64 * NB, WS = BC + 4, TR = SHORT ? 32 : 64, AJ = TR / 32;
   __shared__ __attribute__((aligned(16))) float smem[64 * LS + 32 * WS];
-  __shared__ int prow[64];
-  float* As = smem;            // [64 pairs][32 n]
-  float* Ws = smem + 64 * LS;  // [32 n][BC kk]
+  __shared__ int prow[TR];
+  float* As = smem;            // [TR pairs][32 n]
+  float* Ws = smem + TR * LS;  // [32 n][BC kk]
   int e, m0, cnt, ct;
-  if (!find_unit(g.offsets, g.E, g.ncol, blockIdx.x, e, m0, cnt, ct)) return;
+  if (!find_unit<TR>(g.offsets, g.E, g.ncol, blockIdx.x, e, m0, cnt, ct)) return;
   const int c0 = ct * BC;  // output (kk) tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ln = lane & 31, hf = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = SHORT ? 0 : wave >> 1, wn = wave & 1, wk = SHORT ? wave >> 1 : 0;
   const bool rows_here = m0 + 32 * wm < cnt;  // wave-uniform
-  __shared__ float srow[64];   // the rows' scale factors: one request per row here, not sixteen serial ones per lane at the end
-  if (tid < 64) {
+  __shared__ float srow[TR];   // the rows' scale factors: one request per row here, not sixteen serial ones per lane at the end
+  if (tid < TR) {
     const int pp = (m0 + tid < cnt) ? g.perm[g.offsets[e] + m0 + tid] : -1;
     prow[tid] = pp;
     srow[tid] = (pp >= 0 && g.scale) ? g.scale[pp] : 1.f;
@@ -774,18 +794,18 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
   constexpr unsigned PASTO = 0x80000000u;
   const __amdgpu_buffer_rsrc_t a_rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.A, 0, 0x7ffffffe, 0x00020000);
   const __amdgpu_buffer_rsrc_t w_rs = __builtin_amdgcn_make_buffer_rsrc((void*)We, 0, 0x7ffffffe, 0x00020000);
-  unsigned aoffs[2];
+  unsigned aoffs[AJ];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < AJ; ++j) {
     const int pp = prow[sr + 32 * j];
     aoffs[j] = pp >= 0 ? (unsigned)(((int64_t)(pp / g.a_div) * g.lda + sc) * 4) : PASTO;
   }
   const bool cin = c0 + wc < g.Kd;
-  float4 ast[2], wst[32 / RPP];
+  float4 ast[AJ], wst[32 / RPP];
   auto prefetch = [&](int nb) {   // (nb past the contraction: every piece reads zeros)
     const bool nin = nb + sc < g.N;
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < AJ; ++j)
       ast[j] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(a_rs, (int)((nin && aoffs[j] != PASTO) ? aoffs[j] + 4u * nb : PASTO), 0, 0));
 #pragma unroll
     for (int j = 0; j < 32 / RPP; ++j) {
@@ -795,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
   };
   auto commit = [&]() {
 #pragma unroll
-    for (int j = 0; j < 2; ++j) st4(&As[(sr + 32 * j) * LS + sc], ast[j]);
+    for (int j = 0; j < AJ; ++j) st4(&As[(sr + 32 * j) * LS + sc], ast[j]);
 #pragma unroll
     for (int j = 0; j < 32 / RPP; ++j) st4(&Ws[(wrow_ + RPP * j) * WS + wc], wst[j]);
   };
@@ -809,10 +829,10 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
     __syncthreads();
     prefetch(nb + 32);
     if (!rows_here) continue;  // a tail tile with at most 32 pairs: this wave's row half is empty
-    const float* ar = &As[(32 * wm + ln) * LS + 16 * hf];
-    const float* wc_ = &Ws[(16 * hf) * WS + 32 * NB * wn + ln];
+    const float* ar = &As[(32 * wm + ln) * LS + 16 * hf + (SHORT ? 8 * wk : 0)];
+    const float* wc_ = &Ws[(16 * hf + (SHORT ? 8 * wk : 0)) * WS + 32 * NB * wn + ln];
 #pragma unroll
-    for (int s4 = 0; s4 < 4; ++s4) {
+    for (int s4 = 0; s4 < (SHORT ? 2 : 4); ++s4) {
       const float4 a = ld4(ar + 4 * s4);
 #pragma unroll
       for (int x = 0; x < 4; ++x) {
@@ -820,6 +840,18 @@ __global__ __launch_bounds__(256, 2) void grouped_nn_kernel(GemmParams g) {
         for (int j = 0; j < NB; ++j) acc[j] = mfma32(f4(a, x), wc_[(4 * s4 + x) * WS + 32 * j], acc[j]);
       }
     }
+  }
+  if (SHORT) {  // acc(k-half 0) + acc(k-half 1), through the staging space
+    __syncthreads();
+    float* red = smem + wn * (16 * 64);
+    if (wk == 1) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[0][r];
+    }
+    __syncthreads();
+    if (wk == 1) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][r] += red[r * 64 + lane];
   }
 #pragma unroll
   for (int j = 0; j < NB; ++j) {
@@ -1435,7 +1467,13 @@ static int grouped_nt_impl(const char* who, const float* A, int64_t lda, int a_d
       hipLaunchKernelGGL(grouped_nt_wide_kernel, dim3((unsigned)((P + 63) / 64 + E) * g.ncol + (unsigned)g.slots / 2), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   else
     { AMK_CHECK_SUPPORTED(g.a_bytes < 0x7fff0000ll && (int64_t)N * Kd * 4 < 0x7fff0000ll, "%s: A and one expert's weights must span < 2 GiB", who);
-      g.ncol = (N + 63) / 64; hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+      g.ncol = (N + 63) / 64;
+      // few tiles per CU (all resident at once): 32-pair tiles, twice as many workgroups half as long (AMK_MOE_SHORT=0: never)
+      static const bool short_ok = !(getenv("AMK_MOE_SHORT") && atoi(getenv("AMK_MOE_SHORT")) == 0);
+      if (short_ok && N <= 64 && Kd >= 256 && (P + 63) / 64 < 16 * wg_slots() / 2)
+        hipLaunchKernelGGL((grouped_nt_kernel<1, true>), dim3(2 * mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+      else
+        hipLaunchKernelGGL(grouped_nt_kernel<1>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
   AMK_CHECK_LAUNCH(who);
   return AMK_OK;
 }
@@ -1474,7 +1512,14 @@ static int grouped_nn_impl(const char* who, const float* A, int64_t lda, int a_d
     amk_set_error("%s: A and one expert's weights must span < 2 GiB", who);
     return AMK_EUNSUPPORTED;
   } else if (Kd > 64) { g.ncol = (Kd + 127) / 128; hipLaunchKernelGGL(grouped_nn_kernel<2>, dim3(mt * g.ncol), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
-  else { g.ncol = 1; hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt), dim3(256), 0, static_cast<hipStream_t>(stream), g); }
+  else {
+    g.ncol = 1;
+    static const bool short_ok = !(getenv("AMK_MOE_SHORT") && atoi(getenv("AMK_MOE_SHORT")) == 0);
+    if (short_ok && N >= 256 && (P + 63) / 64 < 16 * wg_slots() / 2)
+      hipLaunchKernelGGL((grouped_nn_kernel<1, true>), dim3(2 * mt), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+    else
+      hipLaunchKernelGGL(grouped_nn_kernel<1>, dim3(mt), dim3(256), 0, static_cast<hipStream_t>(stream), g);
+  }
   AMK_CHECK_LAUNCH(who);
   return AMK_OK;
 }
