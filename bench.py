@@ -247,7 +247,7 @@ def agent_block(dev, iters, batch=64):
             "measured_copy_gbs": copy_gbs, "kernels": rows}
 
 
-def vitmoe_block(dev, batch=64, steps=3):
+def vitmoe_block(dev, batch=64, steps=10):
     """Secondary, informational: BASELINE.json configs[3] (ViTMoE dim 1024, patch 32, depth 6, 32 experts top-2,
     SwitchHead h 8) forward + backward at batch 64, with HIP events around every routed-expert launch.
     Grouped expert GEMMs are credited 2*P*N*K FLOP (P routed pairs: the reference's work, also where a launch marked
@@ -268,7 +268,7 @@ def vitmoe_block(dev, batch=64, steps=3):
         vm.zero_grad(set_to_none=True)
         torch.nn.functional.cross_entropy(vm(imgs), labels).backward()
 
-    for _ in range(2):
+    for _ in range(3):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
