@@ -68,6 +68,8 @@ class GradReducer:
         self.avg_in_collective = (not self.alone) and dist.get_backend(process_group) == "nccl"
         self.side = torch.cuda.Stream(device=dev) if self.on_gpu else None
         self.sync_step = True
+        self.active = False
+        self._warned_idle = False
         self.static_unused = bool(static_unused)
         # direct_grads: the weight-gradient kernels of amk.ops write a parameter's FIRST gradient of a step straight into its
         # (zeroed) bucket view -- claim() / wrote() below -- instead of returning a tensor for autograd to add to it: one
@@ -117,12 +119,15 @@ class GradReducer:
         """Make every rank start from rank `src`'s parameters (what DDP does at wrap time)."""
         if not self.alone:
             for p in self.params:
-                dist.broadcast(p.data, src=src, group=self.group)
+                # through p.detach(), not p.data: the write bumps p._version, which is what version-checked copies of a
+                # parameter (the bf16 copies of amk.optim.FlatAdam(bf16_shadow=True)) key on
+                dist.broadcast(p.detach(), src=src, group=self.group)
 
     # ------------------------------------------------------------------ per step
     def begin(self, sync=True):
         """Call before backward.  sync=False: accumulate locally, no communication this step."""
         self.sync_step = sync
+        self.active = True   # a backward owned by this reducer is (about to be) running: claim() hands out views
         self._next = 0
         self.launch_order = []
         for b in self.buckets:
@@ -153,7 +158,9 @@ class GradReducer:
         """The bucket view to write p's gradient into, if this is the first gradient p receives since the bucket was zeroed
         (else None: the caller returns a tensor and autograd accumulates).  The caller must call wrote(p) after launching
         the kernel that fills the view."""
-        if not self.direct_grads:
+        if not self.direct_grads or not self.active:
+            # outside begin() ... finish() a backward is not this reducer's (torch.autograd.grad on the model, a
+            # probe): the caller returns tensors and autograd does what it always does
             return None
         ent = self._bucket_of.get(p)
         if ent is None:
@@ -227,6 +234,7 @@ class GradReducer:
 
     def finish(self, detach_unused=True):
         """Call after backward, before clip / optimizer.step()."""
+        self.active = False
         if not self.sync_step:
             return
         for b in self.buckets:
@@ -258,7 +266,19 @@ class GradReducer:
         fire would skip an update the others apply, and the replicas drift apart).  Static mode: one blocking MAX
         all-reduce of the fired flags at the first synchronised step, reused afterwards; else one per step."""
         recorded = all(b.static_unused is not None for b in self.buckets)
-        if self.static_unused and recorded:
+        if self.static_unused and recorded and not self.alone:
+            # DDP's static_graph contract: the recorded set stands.  A recorded-USED parameter that did not fire here may
+            # have fired on another rank (its averaged gradient is in the bucket), so it counts as fired; if it fired on
+            # NO rank this step the optimizer applies a zero-gradient update (moment decay, weight decay) where the
+            # reference would skip the parameter -- said once, loudly, since no collective is spent on finding out.
+            idle = [p for b in self.buckets for p, f, u in zip(b.params, b.fired, b.static_unused) if not f and not u]
+            if idle and not self._warned_idle:
+                import warnings
+
+                self._warned_idle = True
+                warnings.warn(f"GradReducer(static_unused=True): {len(idle)} parameter(s) recorded as used received no local "
+                              "gradient this step; they are treated as used (a peer may have produced one).  Call "
+                              "reset_static() if the set of used parameters changed.")
             for b in self.buckets:
                 b.fired = [f or not u for f, u in zip(b.fired, b.static_unused)]
             return

@@ -15,12 +15,16 @@ class GraphedStep:
     the static buffers and launches the graph.  `fn` must not synchronise with the host; optimizers
     need ``capturable=True``."""
 
-    def __init__(self, fn, static_inputs, warmup=3):
+    def __init__(self, fn, static_inputs, warmup=3, before_each=None):
+        """before_each: called on the host before every warm-up run (a train step's schedule tick: the warm-up runs are
+        real optimizer steps)."""
         self.static_inputs = [t.clone() for t in static_inputs]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
+                if before_each is not None:
+                    before_each()
                 fn(*self.static_inputs)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()

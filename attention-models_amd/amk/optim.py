@@ -23,8 +23,13 @@ def _ptr(t):
 
 class FlatAdam:
     def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
-                 capturable=False, bf16_shadow=False):
-        """capturable=True: the per-parameter table {active, lr / bias-correction-1, sqrt(bias-correction-2)} is
+                 capturable=False, bf16_shadow=False, no_decay=()):
+        """decoupled=True: AdamW (torch.optim.AdamW; trainers/vit.py:29, trainers/utils/optimizer.py:14-15).  no_decay: the
+        parameters of the second group of trainers/muse.py:48-58 / trainers/maskgit.py (weight decay 0); every other
+        parameter decays with `weight_decay`.  The decay factor travels in the per-parameter table (lr * wd for AdamW), so
+        it follows the learning rate wherever that lives -- host or device.
+
+        capturable=True: the per-parameter table {active, lr / bias-correction-1, sqrt(bias-correction-2)} is
         computed on the device from device-resident step counts and learning rate (a few tiny launches) instead of on
         the host, so that ``step`` can be captured into a HIP graph and replayed (amk/graphs.py): nothing in it then
         reads host memory.  The set of parameters that receive gradients must not change between replays.
@@ -35,8 +40,6 @@ class FlatAdam:
         back (load_state_dict, manual init) must call ``refresh_shadow()``."""
         if not reducer.on_gpu:
             raise RuntimeError("FlatAdam runs on MI355X (HIP) parameters only; use torch.optim on CPU")
-        if capturable and decoupled and weight_decay:
-            raise ValueError("FlatAdam(capturable=True): decoupled weight decay takes lr as a launch argument")
         self.red = reducer
         self.capturable = bool(capturable)
         self._lr = float(lr)
@@ -46,6 +49,8 @@ class FlatAdam:
         dev = reducer.buckets[0].flat.device
         self.params = [p for b in reducer.buckets for p in b.params]
         self.steps = np.zeros(len(self.params), dtype=np.int64)
+        skip = {id(p) for p in no_decay}
+        self.wd = np.array([0.0 if id(p) in skip else float(weight_decay) for p in self.params], dtype=np.float64)
         self.flat_p, self.m, self.v, self.seg, self.flat_p16 = [], [], [], [], []
         pid = 0
         for b in reducer.buckets:
@@ -78,6 +83,7 @@ class FlatAdam:
             self.steps_dev = torch.zeros(len(self.params), device=dev, dtype=torch.float64)
             self.lr_dev = torch.full((), float(lr), device=dev, dtype=torch.float64)
             self._fired_host, self._fired_dev = None, None
+            self.wd_dev = torch.tensor(self.wd, device=dev)
 
     def enable_shadow(self):
         """Start keeping bf16 copies of the parameters (see ``bf16_shadow``); idempotent."""
@@ -129,6 +135,7 @@ class FlatAdam:
         tab[:, 0] = self._fired_dev
         tab[:, 1] = self.lr_dev / (1.0 - torch.pow(torch.full_like(t, b1), t))
         tab[:, 2] = torch.sqrt(1.0 - torch.pow(torch.full_like(t, b2), t))
+        tab[:, 3] = self.wd_dev * self.lr_dev if self.decoupled else self.wd_dev
         return tab
 
     def step(self, max_norm=None, lr=None):
@@ -155,6 +162,7 @@ class FlatAdam:
             tab[:, 0] = fired
             tab[:, 1] = self.lr / (1.0 - b1 ** t)
             tab[:, 2] = np.sqrt(1.0 - b2 ** t)
+            tab[:, 3] = self.wd * self.lr if self.decoupled else self.wd
             tab_d.copy_(tab_h, non_blocking=True)
             done.record()
         clip = float(max_norm) if max_norm else 0.0
@@ -166,7 +174,7 @@ class FlatAdam:
                 _ptr(self.flat_p[k]), _ptr(b.flat), _ptr(self.m[k]), _ptr(self.v[k]), b.flat.numel(),
                 _ptr(self.seg[k]), _ptr(tab_d), _ptr(self.partials), self.partials.numel(),
                 clip, float(self.lr), float(b1), float(b2), float(self.eps), float(self.weight_decay),
-                1 if self.decoupled else 0, _ptr(self.norm) if k == 0 else _ptr(None),
+                3 if self.decoupled else 2, _ptr(self.norm) if k == 0 else _ptr(None),
                 _ptr(self.flat_p16[k]) if self.flat_p16 else _ptr(None), stream)
             _lib.check(rc, "amk_adam_flat_step")
         red.mark_zeroed()

@@ -40,11 +40,215 @@ def cosine_warmup_lr(step, base_lr, t_initial, warmup_t, warmup_lr_init=1e-6, lr
     return lr_min + 0.5 * (base_lr - lr_min) * (1.0 + math.cos(math.pi * t / t_initial))
 
 
+def cosine_with_warmup_factor(step, num_warmup_steps, num_training_steps, num_cycles=0.5):
+    """The lr lambda of transformers.get_cosine_schedule_with_warmup (trainers/vit.py:33,
+    trainers/utils/scheduler.py:12-13); tests/test_host_logic.py checks it against the library."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+def constant_with_warmup_factor(step, num_warmup_steps):
+    """transformers.get_constant_schedule_with_warmup (trainers/utils/scheduler.py:10-11)."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1.0, num_warmup_steps))
+    return 1.0
+
+
+class SupervisedTrainStep:
+    """The single-model train loops of the reference -- trainers/vit.py:66-76 (ViT / ViTMoE classifier),
+    trainers/muse.py:88-97, trainers/maskgit.py (masked-token decoder over a FROZEN vq) -- one process per GPU:
+
+        with accelerator.accumulate(model):            sync = every accum_steps-th call; else no communication
+            with accelerator.autocast(): out = model(...)
+            loss = ...
+            accelerator.backward(loss)                 loss / accum_steps; gradients all-reduced by amk.dp.GradReducer
+            if sync and max_grad_norm: clip_grad_norm_       (bucketed RCCL all-reduce on a side stream under backward)
+            optim.step(); scheduler.step(global_step); optim.zero_grad()       (all three only on sync iterations)
+
+    Subclasses give ``_loss(*batch)``.  Parameters with requires_grad False (the frozen vq of MUSE) are in no bucket;
+    parameters that never receive a gradient (SwitchHeadAttention.W_d, models/switchhead_attention.py:80-87) travel as
+    zeros, are recorded as static-unused by the first synchronised step and are skipped by the optimizer, as torch
+    skips ``.grad is None``.  The optimizer is torch.optim.AdamW's arithmetic on amk.optim.FlatAdam (clip + update +
+    zeroing in two passes over the flat buckets; torch.optim on CPU tensors); `no_decay`: name fragments whose parameters
+    get weight decay 0 (trainers/muse.py:48-58).
+
+    Schedule: the reference calls ``scheduler.step(self.global_step)`` after the optimizer, on sync iterations only
+    (accelerate skips it otherwise), and LambdaLR starts the optimizer at factor(0): the optimizer step of iteration g
+    runs with base_lr * factor(g'), g' the PREVIOUS sync iteration's index (0 for the first).
+
+    capture(): the device side of one optimizer step -- forward, backward, the buckets' all-reduces on the side stream,
+    clip, AdamW -- as ONE HIP-graph replay.  With more than one rank the RCCL collectives are captured with it (torch
+    captures ProcessGroupNCCL collectives; the side stream joins the capture through the reducer's ready events), so a
+    data-parallel step is not host-paced; over gloo (CPU tests, the shared-GPU rehearsal) capture() refuses."""
+
+    def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, no_decay=(), decoupled=True,
+                 schedule="cosine_with_warmup", warmup_steps=0, total_steps=1, max_grad_norm=1.0, accum_steps=1,
+                 autocast=None, capturable=False, bucket_bytes=32 << 20, fused_optimizer=None, direct_grads=None,
+                 communicate_when_alone=False):
+        self.model = model
+        self.base_lr, self.schedule = float(lr), schedule
+        self.warmup_steps, self.total_steps = int(warmup_steps), int(total_steps)
+        self.max_grad_norm, self.accum_steps, self.autocast = max_grad_norm, int(accum_steps), autocast
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        on_gpu = named[0][1].is_cuda
+        # communicate_when_alone: a world of one rank issues its (identity) RCCL all-reduces anyway -- how the one-GPU test
+        # box exercises the collective path, eager and captured
+        self.red = GradReducer([p for _, p in named], bucket_bytes, communicate_when_alone=communicate_when_alone,
+                               direct_grads=on_gpu if direct_grads is None else bool(direct_grads))
+        skip = [p for n, p in named if any(frag in n for frag in no_decay)]
+        self.fused_optimizer = on_gpu if fused_optimizer is None else bool(fused_optimizer)
+        if self.fused_optimizer:
+            self.optim = FlatAdam(self.red, lr=lr, betas=betas, weight_decay=weight_decay, decoupled=decoupled,
+                                  capturable=capturable, bf16_shadow=autocast == torch.bfloat16, no_decay=skip)
+        else:
+            ids = {id(p) for p in skip}
+            groups = [dict(params=[p for _, p in named if id(p) not in ids], weight_decay=weight_decay),
+                      dict(params=skip, weight_decay=0.0)]
+            cls = torch.optim.AdamW if decoupled else torch.optim.Adam
+            kw = dict(capturable=True) if capturable else {}
+            self.optim = cls([g for g in groups if g["params"]], betas=betas,
+                             lr=torch.tensor(float(lr), device=named[0][1].device) if capturable else lr, **kw)
+        self.red.broadcast_parameters()
+        if self.fused_optimizer:
+            self.optim.refresh_shadow()
+        self.global_step = 0
+        self._micro = 0          # accelerator.step: calls of accumulate() so far
+        self._lr_arg = 0         # the index the scheduler was last stepped with
+        self._graph = None
+        self.last_lr = None
+
+    # ---- what a subclass provides
+    def _loss(self, *batch):
+        raise NotImplementedError
+
+    # ---- schedule
+    def lr_factor(self, step):
+        if self.schedule == "cosine_with_warmup":
+            return cosine_with_warmup_factor(step, self.warmup_steps, self.total_steps)
+        if self.schedule == "constant_with_warmup":
+            return constant_with_warmup_factor(step, self.warmup_steps)
+        if self.schedule in (None, "constant"):
+            return 1.0
+        raise ValueError(f"unknown schedule {self.schedule!r}")
+
+    def _set_lr(self):
+        lr = self.last_lr = self.base_lr * self.lr_factor(self._lr_arg)
+        if isinstance(self.optim, FlatAdam):
+            self.optim.lr = lr
+            return
+        for g in self.optim.param_groups:
+            if torch.is_tensor(g["lr"]):
+                g["lr"].fill_(lr)
+            else:
+                g["lr"] = lr
+
+    def _amp(self):
+        import contextlib
+
+        if self.autocast is None:
+            return contextlib.nullcontext()
+        dev = "cuda" if self.red.on_gpu else "cpu"
+        return torch.autocast(dev, dtype=self.autocast)
+
+    # ---- the step
+    def step_body(self, sync, *batch):
+        """Everything of one iteration that runs on the device: what capture() records (sync=True)."""
+        self.red.begin(sync)
+        loss = self._loss(*batch)
+        (loss if self.accum_steps == 1 else loss / self.accum_steps).backward()
+        self.red.finish()
+        if sync:
+            if isinstance(self.optim, FlatAdam):
+                self.optim.step(max_norm=self.max_grad_norm)
+            else:
+                if self.max_grad_norm:
+                    torch.nn.utils.clip_grad_norm_(self.red.params, self.max_grad_norm)
+                self.optim.step()
+                self.red.zero_grad()
+        return loss.detach()
+
+    def step(self, *batch):
+        """One iteration of the reference loop on one (micro-)batch.  Returns the loss (device scalar, undivided)."""
+        self._micro += 1
+        sync = self._micro % self.accum_steps == 0
+        if sync:
+            self._set_lr()
+        g = self._graph
+        if g is not None and sync and self.accum_steps == 1 and len(batch) == len(g.static_inputs) and all(
+                a.shape == b.shape for a, b in zip(batch, g.static_inputs)):
+            loss = g.replay(*batch)
+        else:
+            loss = self.step_body(sync, *batch)
+        if sync:
+            self._lr_arg = self.global_step      # scheduler.step(self.global_step)
+        self.global_step += 1
+        return loss
+
+    def _tick(self):
+        self._micro += 1
+        self._set_lr()
+        self._lr_arg = self.global_step
+        self.global_step += 1
+
+    def capture(self, *batch, warmup=2):
+        """Capture step_body(True, *batch) into a HIP graph (accum_steps 1); step() then replays it for batches of these
+        shapes.  `warmup` eager steps run first: real optimizer steps, with their schedule ticks."""
+        from .graphs import GraphedStep
+
+        if self.accum_steps != 1:
+            raise RuntimeError("capture(): gradient accumulation steps run eagerly")
+        if not self.red.alone and not self.red.avg_in_collective:
+            raise RuntimeError("capture(): only RCCL (backend 'nccl') collectives can be captured into a HIP graph")
+        self._graph = None
+        self._graph = GraphedStep(lambda *b: self.step_body(True, *b), list(batch), warmup=warmup, before_each=self._tick)
+
+    def release_graph(self):
+        self._graph = None
+
+    def save_ckpt(self, path, config=None):
+        """trainers/utils/base_trainer.py:92-107: {'step', 'state_dict', 'config'}, main process only."""
+        import torch.distributed as dist
+
+        if dist.is_initialized() and dist.get_rank() != 0:
+            return
+        torch.save({"step": self.global_step, "config": config,
+                    "state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()}}, path)
+
+
+class ClassifierTrainStep(SupervisedTrainStep):
+    """trainers/vit.py: AdamW(lr, betas) -- torch's default weight decay 0.01 (:29) --, CrossEntropyLoss (:31) on the
+    logits computed under autocast (:67-71: the loss itself sits outside the autocast block), cosine schedule with warm-up
+    (:33).  BASELINE.json configs[1] (ViT) and configs[3] (ViTMoE)."""
+
+    def _loss(self, imgs, target):
+        with self._amp():
+            out = self.model(imgs)
+        return F.cross_entropy(out, target)
+
+
+class MaskedTokenTrainStep(SupervisedTrainStep):
+    """trainers/muse.py:45-97 / trainers/maskgit.py: ``loss = model(text, img)`` under autocast, the model's vq frozen
+    (models/model_factory.py freeze_model: not in any bucket), AdamW with weight decay 0 on biases / LayerNorm gains /
+    embeddings (:48-58).  `text` here is the text tower's output (amk.models.muse.MUSE takes CLIP's hidden states: the tower
+    itself is a download); for a MaskGit-style model without text pass a 1-tuple batch."""
+
+    NO_DECAY = ("bias", "layer_norm.weight", "embeddings.weight")
+
+    def __init__(self, model, weight_decay=0.0, no_decay=NO_DECAY, schedule="constant_with_warmup", **kw):
+        super().__init__(model, weight_decay=weight_decay, no_decay=no_decay, schedule=schedule, **kw)
+
+    def _loss(self, *batch):
+        with self._amp():
+            return self.model(*batch)
+
+
 class VQGANTrainStep:
     def __init__(self, model, discr, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0,
                  adv_loss_weight=0.1, logit_laplace_weight=1.0, max_grad_norm=1.0,
                  warmup_steps=50000, decay_steps=100000, gp_lambda=10.0, bucket_bytes=32 << 20,
-                 share_forward=False, capturable=False, fused_optimizer=None, autocast=None):
+                 share_forward=False, capturable=False, fused_optimizer=None, autocast=None, communicate_when_alone=False):
         self.model, self.discr = model, discr
         # autocast: None (f32, the parity mode) or a dtype (torch.bfloat16): the forward passes and losses of both phases
         # run inside torch.autocast as the reference's do (trainers/vitgqgan.py:149,168 `accelerator.autocast()`);
@@ -56,8 +260,8 @@ class VQGANTrainStep:
         fused = next(model.parameters()).is_cuda
         # direct_grads: the Linear layers' weight-gradient kernels write straight into the generator's gradient buckets (no
         # weight is shared between two such layers in ViTVQGAN); the discriminator's convolutions go through autograd
-        self.g_red = GradReducer(model.parameters(), bucket_bytes, direct_grads=fused)
-        self.d_red = GradReducer(discr.parameters(), bucket_bytes)
+        self.g_red = GradReducer(model.parameters(), bucket_bytes, direct_grads=fused, communicate_when_alone=communicate_when_alone)
+        self.d_red = GradReducer(discr.parameters(), bucket_bytes, communicate_when_alone=communicate_when_alone)
         # fused_optimizer (default on the GPU): amk.optim.FlatAdam -- clip + Adam + zeroing in two passes over the
         # reducer's flat buckets (csrc/optim.hip) instead of clip_grad_norm_ + Adam.step + zero_grad.
         # capturable=True: step counts and learning rate live on the device (FlatAdam(capturable=True), or torch's
@@ -81,6 +285,9 @@ class VQGANTrainStep:
             self.d_optim = torch.optim.Adam(discr.parameters(), lr=lr, **okw)
         self.g_red.broadcast_parameters()
         self.d_red.broadcast_parameters()
+        if self.fused_optimizer:
+            # the bf16 copies were derived from this rank's initial weights; the broadcast has just replaced those
+            self.g_optim.refresh_shadow()
         self.global_step = 0
         # The reference runs the generator forward twice per step on the same images with unchanged
         # generator weights (trainers/vitgqgan.py:149 and :169; only the discriminator steps in
@@ -151,15 +358,21 @@ class VQGANTrainStep:
 
     def capture(self, img, warmup=2):
         """Capture step_body() for batches shaped like `img` into a HIP graph; step() then replays it (the host
-        enqueues one launch instead of ~2500).  Needs capturable=True and a world of one rank (the reducers' RCCL
-        collectives on their side stream are not captured); `warmup` eager steps run first on the capture stream --
-        they are real optimizer steps.  release_graph() returns to eager steps."""
+        enqueues one launch instead of ~2500).  Needs capturable=True.  With several ranks the reducers' RCCL collectives
+        on their side stream are captured WITH the step (the side stream joins the capture through the ready events), so
+        the data-parallel step is one replay per rank too; over gloo it refuses.  `warmup` eager steps run first on the
+        capture stream -- they are real optimizer steps.  release_graph() returns to eager steps."""
         from .graphs import GraphedStep
 
-        if not self.g_red.alone or not self.d_red.alone:
-            raise RuntimeError("VQGANTrainStep.capture: data-parallel steps run eagerly")
+        self._check_capturable("capture")
         self._graph = None
-        self._graph = GraphedStep(lambda x: self.step_body(x), [img], warmup=warmup)
+        self._graph = GraphedStep(lambda x: self.step_body(x), [img], warmup=warmup, before_each=self._tick)
+
+    def _check_capturable(self, what):
+        for red in (self.g_red, self.d_red):
+            if not red.alone and not red.avg_in_collective:
+                raise RuntimeError(f"VQGANTrainStep.{what}: only RCCL (backend 'nccl') collectives can be captured into a "
+                                   "HIP graph; over gloo the data-parallel step runs eagerly")
 
     def release_graph(self):
         self._graph = None
@@ -171,8 +384,7 @@ class VQGANTrainStep:
         `gradient_accumulation_steps`) into a HIP graph; step_accumulated() then replays it.  Same conditions as capture()."""
         from .graphs import GraphedStep
 
-        if not self.g_red.alone or not self.d_red.alone:
-            raise RuntimeError("VQGANTrainStep.capture_accumulated: data-parallel steps run eagerly")
+        self._check_capturable("capture_accumulated")
         n = len(micro_batches)
 
         def body(*xs):
@@ -181,12 +393,21 @@ class VQGANTrainStep:
             return self.step_body(xs[-1], True, n, None)
 
         self._accum_graph = None
-        self._accum_graph = GraphedStep(body, list(micro_batches), warmup=warmup)
+        self._accum_graph = GraphedStep(body, list(micro_batches), warmup=warmup, before_each=lambda: self._tick(n))
+
+    def _tick(self, n=1):
+        """A warm-up step of capture() is a real optimizer step: it gets its learning rate and advances global_step."""
+        self.global_step += n - 1
+        self._set_lr()
+        self.global_step += 1
 
     def step_accumulated(self, micro_batches):
         """One optimizer step over the micro-batches: a replay of capture_accumulated()'s graph when the shapes match, else
-        eager micro-steps."""
+        eager micro-steps.  The reference ticks its schedulers every iteration (trainers/vitgqgan.py:161,187) and the
+        optimizers step at the last micro-batch: the learning rate is the one of that iteration."""
+        self.global_step += len(micro_batches) - 1
         self._set_lr()
+        self.global_step -= len(micro_batches) - 1
         g = getattr(self, "_accum_graph", None)
         if g is not None and len(micro_batches) == len(g.static_inputs) and all(
                 a.shape == b.shape for a, b in zip(micro_batches, g.static_inputs)):

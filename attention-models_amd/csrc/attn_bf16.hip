@@ -545,10 +545,13 @@ extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, co
   const int64_t nwg = (int64_t)B * H * p.nkblk;
   AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_bf16_bwd: grid too large");
   constexpr size_t lds = (size_t)(BKEYS * TSTR + 2 * BKEYS * DSTR + 4 * (32 * KSTR + 32 * TSTR)) * 2 + 2 * 64 * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
+  static bool attr_set[64] = {};   // per device ordinal (the opt-in to > 64 KiB of dynamic LDS is per device)
+  int dev_id = 0;
+  AMK_CHECK_ARG(hipGetDevice(&dev_id) == hipSuccess && dev_id >= 0 && dev_id < 64, "amk_attn_bf16_bwd: no current device");
+  if (!attr_set[dev_id]) {
+    AMK_CHECK_SUPPORTED(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+                        "amk_attn_bf16_bwd: the device refused %zu bytes of dynamic LDS", lds);
+    attr_set[dev_id] = true;
   }
   hipLaunchKernelGGL(attn_bf16_bwd_kernel, dim3((unsigned)nwg), dim3(64 * BW), lds, st, p);
   const int64_t n4 = (int64_t)B * I * H * 16;

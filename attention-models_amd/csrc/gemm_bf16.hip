@@ -516,11 +516,16 @@ extern "C" int amk_gemm_tn_bf16(const void* y, int64_t ldy, const void* x, int64
   p.total = (int)total;
   hipStream_t st = static_cast<hipStream_t>(stream);
   constexpr size_t lds4 = (size_t)2 * 64 * ((128 + 32) + (128 + 32)) * 2, lds8 = (size_t)2 * 64 * ((128 + 32) + (256 + 32)) * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8);
-    attr_set = true;
+  // the opt-in to > 64 KiB of dynamic LDS is per device: one flag per device ordinal, and a refusal is an error here, not
+  // an opaque launch failure later
+  static bool attr_set[64] = {};
+  int dev_id = 0;
+  AMK_CHECK_ARG(hipGetDevice(&dev_id) == hipSuccess && dev_id >= 0 && dev_id < 64, "amk_gemm_tn_bf16: no current device");
+  if (!attr_set[dev_id]) {
+    AMK_CHECK_SUPPORTED(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn_bf16_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds8) == hipSuccess,
+                        "amk_gemm_tn_bf16: the device refused %zu bytes of dynamic LDS", lds8);
+    attr_set[dev_id] = true;
   }
   if (TK == 256) hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 4>), dim3((unsigned)total), dim3(512), lds8, st, p);
   else hipLaunchKernelGGL((gemm_tn_bf16_kernel<2, 2>), dim3((unsigned)total), dim3(256), lds4, st, p);

@@ -50,11 +50,13 @@ struct AdamArgs {
   float *p, *g, *m, *v;
   int64_t nseg;
   const int32_t* seg_param;  // (nseg) parameter index of each segment
-  const float* tab;          // (P, 4): active, lr / bias_correction1, sqrt(bias_correction2), unused
+  const float* tab;          // (P, 4): active, lr / bias_correction1, sqrt(bias_correction2), weight-decay factor (decoupled & 2)
   const float* partials;     // (n_partials) squared-norm partials of ALL buckets of this optimizer
   int n_partials;
   float max_norm, beta1, beta2, eps, weight_decay, lr;
-  int decoupled;             // 0: Adam (L2 term added to the gradient), 1: AdamW
+  int decoupled;             // bit 0: 0 Adam (L2 term added to the gradient), 1 AdamW (p -= lr * wd * p);
+                             // bit 1: the factor comes per parameter from tab[.][3] (wd resp. lr * wd, computed where lr
+                             // lives -- on the device for a graph-captured step) instead of the launch arguments
   float* norm_out;           // (1) the global gradient norm before clipping, or null
   __bf16* p16;               // bf16 copy of the parameters for the mixed-precision GEMMs, refreshed here, or null
 };
@@ -83,13 +85,15 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(AdamArgs a) {
     if (t.x == 0.f) continue;  // no gradient this step: skipped like .grad None
     float4 p = ld4(a.p + off), m = ld4(a.m + off), v = ld4(a.v + off);
     const float step_size = t.y, bc2s = t.z;
+    const bool adamw = (a.decoupled & 1) != 0;
+    const float wdf = (a.decoupled & 2) ? t.w : (adamw ? a.lr * a.weight_decay : a.weight_decay);
 #define AMK_ADAM_ONE(f)                                                   \
     {                                                                     \
       float gg = g.f * coef;                                              \
       float pp = p.f;                                                     \
-      if (a.weight_decay != 0.f) {                                        \
-        if (a.decoupled) pp -= a.lr * a.weight_decay * pp;                \
-        else gg += a.weight_decay * pp;                                   \
+      if (wdf != 0.f) {                                                   \
+        if (adamw) pp -= wdf * pp;                                        \
+        else gg += wdf * pp;                                              \
       }                                                                   \
       const float mm = m.f + omb1 * (gg - m.f);                           \
       const float vv = a.beta2 * v.f + omb2 * gg * gg;                    \

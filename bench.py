@@ -51,6 +51,11 @@ def parse():
     ap.add_argument("--no-kernels", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the informational shared-forward variant")
     ap.add_argument("--no-graph", action="store_true", help="enqueue every step launch by launch instead of replaying one HIP graph")
+    ap.add_argument("--model", default="vqgan", choices=["vqgan", "vit", "vitmoe", "muse"],
+                    help="vqgan (default): the headline, BASELINE.json configs[2].  vit / vitmoe / muse: a SECONDARY line -- the "
+                         "data-parallel classifier step of configs[1] / configs[3] (trainers/vit.py) or the masked-token decoder step "
+                         "of configs[4] (trainers/muse.py) through the same reducer, optimizer and graph capture")
+    ap.add_argument("--autocast", default="none", choices=["none", "bf16"], help="--model vit|vitmoe|muse only")
     return ap.parse_args()
 
 
@@ -304,6 +309,141 @@ def vitmoe_block(dev, batch=64, steps=10):
             "ms_per_step": dt * 1e3, "images_per_s": batch / dt, "kernels": rows}
 
 
+def dp_graph_ok(dev, world):
+    """Can this process group's collectives be captured into a HIP graph?  A pre-flight on a 1-MiB buffer: an all-reduce
+    on a side stream inside a capture, two replays, the result checked; every rank must agree (MIN over ranks), else the
+    data-parallel step runs eagerly.  World of one: nothing to capture."""
+    if world == 1 and not dist.is_initialized():
+        return True, "one rank"
+    if os.environ.get("AMK_DP_GRAPH", "1") != "1":
+        return False, "AMK_DP_GRAPH=0"
+    if dist.get_backend() != "nccl":
+        return False, f"backend {dist.get_backend()} cannot be captured"
+    ok, why = 1.0, "probe passed"
+    try:
+        buf = torch.ones(1 << 18, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        dist.all_reduce(buf, op=dist.ReduceOp.AVG)   # communicator warm-up outside the capture
+        torch.cuda.synchronize()
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream())
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(cap):
+            with torch.cuda.graph(graph, stream=cap):
+                buf.mul_(2.0)
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    dist.all_reduce(buf, op=dist.ReduceOp.AVG)
+                torch.cuda.current_stream().wait_stream(side)
+                buf.add_(1.0)
+        graph.replay()
+        graph.replay()
+        torch.cuda.synchronize()
+        if abs(float(buf[0]) - 7.0) > 1e-6 or abs(float(buf[-1]) - 7.0) > 1e-6:   # ((1*2+1)*2+1)
+            ok, why = 0.0, f"probe replay gave {float(buf[0])}, expected 7"
+    except Exception as e:  # noqa: BLE001 -- any failure means: run eagerly
+        ok, why = 0.0, f"probe raised {type(e).__name__}: {e}"
+    t = torch.tensor([ok], device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if float(t.item()) < 1.0 and ok == 1.0:
+        why = "probe failed on another rank"
+    return float(t.item()) >= 1.0, why
+
+
+SECONDARY = {
+    "vit": dict(metric="ViT 256px classifier train-step images/sec", batch=64,
+                workload="BASELINE.json configs[1]: ViT dim=1024 patch=32 img=256 depth=6 h=16 d=64 (33.6 M parameters); "
+                         "trainers/vit.py step: CE, AdamW (wd 0.01), clip 1.0, cosine schedule with warm-up"),
+    "vitmoe": dict(metric="ViTMoE 256px classifier train-step images/sec", batch=64,
+                   workload="BASELINE.json configs[3]: ViTMoE dim=1024 patch=32 depth=6 n_experts=32 top-2 + SwitchHeadAttention "
+                            "h=8 (240.6 M parameters, 962 MB of gradients per all-reduce); trainers/vit.py step: CE, AdamW, clip, cosine"),
+    "muse": dict(metric="Muse masked-token decoder train-step images/sec", batch=8,
+                 workload="BASELINE.json configs[4]: Muse decoder dim=1024 h=16 depth=22 mult=6 over FROZEN ViTVQGAN codes "
+                          "(1024 tokens, 77 synthetic text positions); trainers/muse.py step: masked-token CE, AdamW, clip"),
+}
+
+
+def secondary_main(args, world, rank, dev, n_ranks_seen):
+    """--model vit | vitmoe | muse: the data-parallel single-model step (amk.train.ClassifierTrainStep /
+    MaskedTokenTrainStep) -- a secondary line, never the headline."""
+    from amk import lib, tuning
+    from amk.train import ClassifierTrainStep, MaskedTokenTrainStep
+
+    lib.load()
+    if os.environ.get("AMK_TUNABLEOP", "1") == "1":
+        tuning.enable_gemm_tuning()
+    spec = SECONDARY[args.model]
+    batch = args.batch if args.batch != 32 else spec["batch"]
+    amp = torch.bfloat16 if args.autocast == "bf16" else None
+    can_graph, graph_why = (False, "--no-graph") if args.no_graph else dp_graph_ok(dev, world)
+    alone_rccl = os.environ.get("AMK_BENCH_RCCL_ALONE", "0") == "1"
+    kw = dict(capturable=can_graph, autocast=amp, communicate_when_alone=alone_rccl, max_grad_norm=1.0)
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(1234 + rank)
+    if args.model == "muse":
+        from amk.models import MUSE, ViTVQGAN
+
+        vq = ViTVQGAN(VIT, CODEBOOK)
+        model = MUSE(dim=1024, vq=vq, n_heads=16, d_head=64, depth=22, mult=6).to(dev)
+        step = MaskedTokenTrainStep(model, lr=1e-4, weight_decay=0.0, warmup_steps=1000, **kw)
+        data = (torch.randn(batch, 77, 768, generator=g).to(dev), torch.rand(batch, 3, 256, 256, generator=g).to(dev))
+    else:
+        from amk.models import ViT, ViTMoE
+
+        if args.model == "vit":
+            model = ViT(dim=1024, image_size=256, patch_size=32, n_heads=16, d_head=64, depth=6, mlp_dim=2048, dropout=0.0,
+                        num_classes=1000).to(dev)
+        else:
+            model = ViTMoE(dim=1024, image_size=256, patch_size=32, n_heads=8, d_head=64, depth=6, n_experts=32, sel_experts=2,
+                           dropout=0.0, num_classes=1000).to(dev)
+        step = ClassifierTrainStep(model, lr=1e-4, warmup_steps=1000, total_steps=100000, **kw)
+        data = (torch.randn(batch, 3, 256, 256, generator=g).to(dev), torch.randint(0, 1000, (batch,), generator=g).to(dev))
+    nparam = sum(p.numel() for p in step.red.params)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    note(f"rank {rank}/{world}: {args.model} built ({nparam / 1e6:.1f} M trainable parameters), batch {batch}/GPU")
+    for _ in range(max(args.warmup, 2)):   # (step 0 records the static-unused parameters; overlap starts with step 1)
+        step.step(*data)
+    graph = "eager"
+    if can_graph:
+        step.capture(*data)
+        graph = "one HIP-graph replay per step" + (" (RCCL all-reduces captured inside)" if not step.red.alone else "")
+    note(f"warm-up done ({graph}; {graph_why})")
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step.step(*data)
+    t_host = time.perf_counter() - t0
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": spec["metric"], "value": batch * world * args.steps / dt, "unit": "images/s", "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "host_enqueue_ms": t_host / args.steps * 1e3, "step_launch": graph, "graph_decision": graph_why,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if amp is None else "bf16 (autocast)", "data": "synthetic N(0,1) images, random-init weights",
+            "secondary": True,
+            "config": {"workload": spec["workload"], "global_batch": batch * world, "batch_per_gpu": batch,
+                       "parallelism": f"dp{world}", "final_loss": float(loss),
+                       "gradient_bytes_per_allreduce": step.red.grads_nbytes(), "buckets": len(step.red.buckets),
+                       "static_unused_parameters": len(step.red.unused_parameters()) if step._graph is None else None}}),
+            flush=True)
+    if world > 1 or dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: start the N rank processes from here.  The parent
     never touches HIP (no torch.cuda call), passes its own flags through, relays rank 0's JSON line and
@@ -365,7 +505,19 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
+    alone_rccl = world == 1 and os.environ.get("AMK_BENCH_RCCL_ALONE", "0") == "1"
+    if alone_rccl:
+        # one rank that communicates anyway: the RCCL path (eager or captured) on a one-GPU box
+        import socket
+
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     n_ranks_seen = dist.get_world_size() if world > 1 else 1
+    if args.model != "vqgan":
+        return secondary_main(args, world, rank, dev, n_ranks_seen)
 
     from amk import lib
     from amk.models import ViTVQGAN
@@ -386,8 +538,10 @@ def main():
     # one rank: the device side of a step (both phases, both optimizers) is captured into a HIP graph after the
     # warm-up and replayed -- the host then enqueues one launch per step instead of ~2500 (tools/host_vs_gpu.py:
     # 92.7 ms of host work per step in round 2); N ranks: eager steps (the reducers' RCCL collectives run on a side stream)
-    use_graph = world == 1 and not args.no_graph
-    trainer = VQGANTrainStep(model, discr, capturable=use_graph)
+    # N ranks over RCCL: the same single replay, with the reducers' all-reduces (side stream) captured inside it -- after
+    # a pre-flight that captures and replays one small all-reduce on every rank (dp_graph_ok); over gloo (rehearsal): eager
+    use_graph, graph_why = (False, "--no-graph") if args.no_graph else dp_graph_ok(dev, world)
+    trainer = VQGANTrainStep(model, discr, capturable=use_graph, communicate_when_alone=alone_rccl)
     g = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, VIT["img_size"], VIT["img_size"], generator=g).to(dev)
 
@@ -398,11 +552,14 @@ def main():
 
     from amk import ops as amk_ops
 
+    host_enqueue = [None]
+
     def timed_steps(n):
         sync()
         t0 = time.perf_counter()
         for _ in range(n):
             logs = trainer.step(imgs)
+        host_enqueue[0] = (time.perf_counter() - t0) / n   # host time to ENQUEUE a step (before the synchronise)
         sync()
         return time.perf_counter() - t0, logs
 
@@ -414,6 +571,7 @@ def main():
     note("warm-up done" + (" (step captured into a HIP graph)" if use_graph else ""))
     # ---- the headline: EXACTLY --steps steps, no instrumentation, barrier + synchronize on both sides
     dt, logs = timed_steps(args.steps)
+    host_enqueue_ms = host_enqueue[0] * 1e3
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -559,6 +717,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
+            "host_enqueue_ms": host_enqueue_ms,
+            "step_launch": ("one HIP-graph replay per step" + (" (RCCL all-reduces captured inside)" if world > 1 or alone_rccl else ""))
+                           if use_graph else "eager",
+            "graph_decision": graph_why,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -611,7 +773,36 @@ def main():
                 "kernels": [dict(kernel=r["kernel"], frac=r["frac_of_f32_mfma_peak"], achieved=r["tflops"],
                                  avg_launch_ms=r["avg_ms"], launches_per_step=r["launches_per_step"]) for r in timed],
             }
+            # the same fractions as flat scalars (a nested list does not survive every parser): BASELINE's metric names
+            # "attn+VQ kernel %roofline", so each of them is a key of `roofline` itself
+            by = {r["kernel"]: r for r in timed}
+            flat = {"frac_attn_fwd": "attn_fwd_kernel", "frac_attn_fwd_keep": "attn_fwd_keep_kernel", "frac_vq": "vq_lookup_fwd"}
+            for key, name in flat.items():
+                if name in by:
+                    line["roofline"][key] = by[name]["frac_of_f32_mfma_peak"]
+            bw = [r for n, r in by.items() if n.startswith("attn_bwd")]
+            if bw:
+                line["roofline"]["frac_attn_bwd"] = max(bw, key=lambda r: r["ms_per_step"])["frac_of_f32_mfma_peak"]
+            if traffic:
+                algo_bytes = 16.0 * args.batch * VIT["n_heads"] * VIT["d_head"] * 2 * T_   # 16*B*h*d*(I+J)
+                line["roofline"]["algorithmic_bytes"] = algo_bytes
+                line["roofline"]["traffic_ratio_vs_algorithmic"] = traffic / algo_bytes
             line["kernels_in_step"] = timed
+        if kernels:
+            for key, name in (("frac_attn_fwd_back_to_back", "attn_fwd_kernel"), ("frac_attn_fwd_keep_back_to_back", "attn_fwd_keep_kernel"),
+                              ("frac_attn_bwd_back_to_back", "attn_bwd_fused_kernel(kept scores)" if amk_ops.ATTENTION_KEEP_SCORES else "attn_bwd_fused_kernel"),
+                              ("frac_vq_back_to_back", "vq_lookup_fwd (prep+argmin+finalize)")):
+                hit = [r for r in kernels if r["kernel"] == name]
+                if hit and "roofline" in line:
+                    line["roofline"][key] = hit[0]["frac_of_f32_mfma_peak"]
+        v16 = variants.get("variant_bf16_autocast")
+        if v16:
+            # the reference's shipped precision as top-level scalars (never `value`: the headline is f32)
+            line["bf16_images_per_s"] = v16["value"]
+            line["bf16_ms_per_step"] = v16["ms_per_step"]
+            ks = v16.get("roofline_bf16", {}).get("kernels", [])
+            if len(ks) >= 2:
+                line["bf16_frac_attn_fwd"], line["bf16_frac_attn_bwd"] = ks[0]["frac"], ks[1]["frac"]
         line.update(variants)
         if kernels:
             line["kernels_microbench"] = kernels
@@ -622,7 +813,7 @@ def main():
         if cpu:
             line["cpu_baseline"] = cpu
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or dist.is_initialized():
         # teardown in a defined order: rank 0's post-headline work (kernel micro-benchmarks, the JSON line) is done
         # before any rank leaves the group -- the other ranks wait here instead of tearing RCCL down under it
         dist.barrier()

@@ -414,7 +414,10 @@ int amk_geglu_bwd(const float* ab, const float* d_out, int64_t M, int H, float* 
  *                        and grad is left zeroed (all parameters).  torch.optim.Adam / AdamW arithmetic.
  * Buffers are flat fp32 arrays of n elements, n a multiple of 256; the i-th segment of 256 elements
  * belongs to parameter seg_param[i]; param_tab is (P, 4) floats per step: {active (0 / 1),
- * lr / (1 - beta1^t), sqrt(1 - beta2^t), unused} with t the parameter's own step count.
+ * lr / (1 - beta1^t), sqrt(1 - beta2^t), weight-decay factor} with t the parameter's own step count.
+ * `decoupled`: bit 0 selects AdamW (1) or Adam-with-L2 (0); bit 1 set = the decay factor is read per parameter from
+ * param_tab[.][3] (wd for Adam, lr * wd for AdamW: per-group weight decay as trainers/muse.py:48-58 sets it up, and a
+ * learning rate that lives on the device for a graph-captured step) instead of the `lr` / `weight_decay` arguments.
  * Inactive parameters (no gradient this step) are left untouched, as optimizers skip .grad None.
  * -------------------------------------------------------------------------- */
 int amk_opt_num_partials(void);

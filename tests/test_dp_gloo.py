@@ -258,3 +258,91 @@ def test_static_unused_parameters_do_not_block_and_are_decided_globally(tmp_path
     fresh = GatedNet()
     assert not torch.equal(r0["skip.weight"], fresh.skip.weight)   # updated (on both ranks) ...
     assert torch.equal(r0["head.weight"], fresh.head.weight)       # ... and the never-used one untouched
+
+
+# ---------------------------------------------------------------------------------------------
+# The classifier train step (amk/train.py ClassifierTrainStep = trainers/vit.py:66-76: CE, AdamW, clip, cosine schedule)
+# on two ranks.  The network is a CPU stand-in with ViTMoE's distinguishing property under data parallelism: a gate
+# `W_d` that only SELECTS (top-k indices, no values used: models/switchhead_attention.py:80-87), so it never receives a
+# gradient -- and it is registered last, i.e. it sits in the FIRST bucket to leave.  (The real ViTMoE runs HIP kernels
+# only: tests/test_dp_rccl_gpu.py runs this same check on it, two ranks sharing the GPU.)
+class _RoutedNet(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.embed = nn.Linear(12, 16)
+        self.experts = nn.Parameter(torch.randn(4, 16, 16) * 0.2)
+        self.head = nn.Linear(16, 5)
+        self.W_d = nn.Linear(16, 4, bias=False)
+
+    def forward(self, x):
+        h = torch.tanh(self.embed(x.flatten(1)))
+        sel = self.W_d(h).topk(2, dim=-1).indices            # values discarded: W_d gets no gradient
+        out = torch.zeros_like(h)
+        for e in range(4):                                     # un-weighted sum over the selected experts
+            hit = (sel == e).any(-1)
+            out = out + hit.unsqueeze(-1) * (h @ self.experts[e])
+        return self.head(out)
+
+
+def _cls_worker(rank, world, port, out_dir):
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "attention-models_amd"))
+    from amk.train import ClassifierTrainStep
+
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(21 + rank)   # different init per rank: the step's broadcast must fix it
+    net = _RoutedNet()
+    # world 1: the same global batch as two accumulation micro-steps (mean of the two half-batch losses = the average of
+    # the two ranks' gradients)
+    ts = ClassifierTrainStep(net, lr=1e-2, warmup_steps=1, total_steps=8, max_grad_norm=1.0, bucket_bytes=512,
+                             accum_steps=1 if world > 1 else 2)
+    assert len(ts.red.buckets) > 2 and any(p is net.W_d.weight for p in ts.red.buckets[0].params)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 8, 3, 2, 2, generator=g)
+    y = torch.randint(0, 5, (3, 8), generator=g)
+    early, w0 = [], net.W_d.weight.detach().clone()
+    finish = ts.red.finish
+
+    def spying_finish(*a, **k):
+        if ts.red.sync_step:
+            early.append(list(ts.red.launch_order))   # buckets that left during backward, before finish()
+        out = finish(*a, **k)
+        if ts.red.sync_step:
+            assert net.W_d.weight.grad is None         # what the optimizer sees: skipped, as in the reference
+            assert net.head.weight.grad is not None
+        return out
+
+    ts.red.finish = spying_finish
+    for s in range(3):
+        if world > 1:
+            ts.step(x[s, 4 * rank: 4 * rank + 4], y[s, 4 * rank: 4 * rank + 4])
+        else:
+            ts.step(x[s, :4], y[s, :4])
+            ts.step(x[s, 4:], y[s, 4:])
+            ts._lr_arg = s            # (the two-rank run's scheduler index counts optimizer steps, this one micro-steps)
+    assert torch.equal(net.W_d.weight, w0)   # skipped like .grad None: no weight decay either
+    torch.save(dict(params={n: p.detach().clone() for n, p in net.named_parameters()}, early=early),
+               os.path.join(out_dir, f"cls_w{world}_r{rank}.pt"))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_classifier_step_with_a_gradient_free_gate(tmp_path):
+    mp.spawn(_cls_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    _cls_worker(0, 1, 0, str(tmp_path))
+    r0 = torch.load(tmp_path / "cls_w2_r0.pt", weights_only=True)
+    r1 = torch.load(tmp_path / "cls_w2_r1.pt", weights_only=True)
+    one = torch.load(tmp_path / "cls_w1_r0.pt", weights_only=True)
+    for n in r0["params"]:
+        assert torch.equal(r0["params"][n], r1["params"][n]), n                                    # replicas in lockstep
+        assert torch.allclose(r0["params"][n], one["params"][n], rtol=2e-4, atol=2e-6), n          # = accumulated run
+    # step 0 records which parameters never fire (nothing can leave before bucket 0, and W_d never completes it);
+    # from step 1 on bucket 0 leaves during backward
+    assert r0["early"][0] == [] and len(r0["early"][1]) >= 1 and r0["early"][1][0] == 0, r0["early"]
+    assert len(r0["early"][2]) >= 1

@@ -193,3 +193,65 @@ def test_switchhead_form_rule(monkeypatch):
     assert not ops._moe_dense_z(256, 128, 16, 32)       # output less than 4x the contraction
     monkeypatch.setattr(ops, "MOE_DENSE_Z", False)
     assert not ops._moe_dense_z(1024, 64, 16, 32)
+
+
+def test_cosine_and_constant_warmup_factors_match_transformers():
+    """trainers/vit.py:33 and trainers/utils/scheduler.py:10-13 use transformers' schedules, stepped with an explicit
+    index (`scheduler.step(self.global_step)`): lr = base * lambda(index)."""
+    transformers = pytest.importorskip("transformers")
+    from amk.train import constant_with_warmup_factor, cosine_with_warmup_factor
+
+    for warm, total in ((0, 10), (5, 20), (7, 7), (3, 4)):
+        p = [torch.nn.Parameter(torch.zeros(1))]
+        opt = torch.optim.AdamW(p, lr=1.0)
+        sch = transformers.get_cosine_schedule_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total)
+        import warnings
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            assert opt.param_groups[0]["lr"] == cosine_with_warmup_factor(0, warm, total)   # LambdaLR starts at lambda(0)
+            for g in range(total + 6):
+                sch.step(g)
+                assert opt.param_groups[0]["lr"] == pytest.approx(cosine_with_warmup_factor(g, warm, total), abs=1e-15), (warm, total, g)
+            opt2 = torch.optim.AdamW(p, lr=1.0)
+            sch2 = transformers.get_constant_schedule_with_warmup(opt2, num_warmup_steps=warm)
+            for g in range(warm + 4):
+                sch2.step(g)
+                assert opt2.param_groups[0]["lr"] == pytest.approx(constant_with_warmup_factor(g, warm), abs=1e-15)
+
+
+def test_classifier_step_follows_the_reference_loop_on_cpu():
+    """ClassifierTrainStep (one rank, CPU tensors -> torch.optim.AdamW inside) against the loop of trainers/vit.py:66-76
+    written out with torch's own pieces and transformers' scheduler: accumulation of 2, clip, AdamW weight decay 0.01,
+    `scheduler.step(global_step)` on sync iterations only (accelerate skips optimizer and scheduler otherwise)."""
+    transformers = pytest.importorskip("transformers")
+    import copy
+    import warnings
+
+    from amk.train import ClassifierTrainStep
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(12, 16), torch.nn.Tanh(), torch.nn.Linear(16, 5))
+    ref = copy.deepcopy(net)
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(4, 3, 2, 2, generator=g) for _ in range(6)]
+    ys = [torch.randint(0, 5, (4,), generator=g) for _ in range(6)]
+    ts = ClassifierTrainStep(net, lr=1e-2, betas=(0.9, 0.95), warmup_steps=2, total_steps=6, max_grad_norm=0.5, accum_steps=2,
+                             bucket_bytes=256)
+    opt = torch.optim.AdamW(ref.parameters(), lr=1e-2, betas=(0.9, 0.95))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        sch = transformers.get_cosine_schedule_with_warmup(opt, num_warmup_steps=2, num_training_steps=6)
+        for gs, (x, y) in enumerate(zip(xs, ys)):
+            loss = ts.step(x, y)
+            want = torch.nn.functional.cross_entropy(ref(x), y)
+            (want / 2).backward()
+            if (gs + 1) % 2 == 0:
+                torch.nn.utils.clip_grad_norm_(ref.parameters(), 0.5)
+                opt.step()
+                sch.step(gs)
+                opt.zero_grad()
+            assert torch.allclose(loss, want, rtol=1e-6, atol=1e-7), gs
+    for a, b in zip(net.parameters(), ref.parameters()):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    assert ts.global_step == 6

@@ -3,7 +3,7 @@
 #   OUT=r3_pmc_dense bash tools/pmc_dense.sh                       (dense GEMMs: tools/kbench_dense.py)
 #   OUT=r3_pmc_bf16 SCRIPT=tools/kbench_attn_bf16.py ARGS="--iters 5" FILTER="attn_bf16 attn_fwd_kernel attn_bwd_fused" bash tools/pmc_dense.sh
 set -e
-R=$GRAFT_REPO_ROOT
+R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${OUT:-r3_pmc_dense}
 SCRIPT=${SCRIPT:-tools/kbench_dense.py}
 ARGS=${ARGS:---only kv,ffn_w12,ffn_w3 --no-fused --no-check --iters 3}
