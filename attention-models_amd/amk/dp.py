@@ -299,5 +299,9 @@ class GradReducer:
         """Parameters that received no gradient since the last zero_grad()."""
         return [p for b in self.buckets for p, f in zip(b.params, b.fired) if not f]
 
+    def static_unused_parameters(self):
+        """The parameters recorded (by the first synchronised step, globally) as never receiving a gradient."""
+        return [p for b in self.buckets if b.static_unused is not None for p, u in zip(b.params, b.static_unused) if u]
+
     def grads_nbytes(self):
         return sum(b.flat.numel() for b in self.buckets) * 4

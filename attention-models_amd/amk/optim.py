@@ -9,6 +9,7 @@ no gradient since the last step are skipped, as torch optimizers skip ``.grad is
 are kept per parameter for the bias corrections.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -22,6 +23,10 @@ def _ptr(t):
 
 
 class FlatAdam:
+    # the decay factor travels in the per-parameter table (needed for no_decay groups and for a device-resident lr);
+    # False: the launch-argument form of the kernel (one weight decay for all, lr from the host)
+    TABLE_WD = os.environ.get("AMK_OPT_TABLE_WD", "1") == "1"
+
     def __init__(self, reducer, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decoupled=False,
                  capturable=False, bf16_shadow=False, no_decay=()):
         """decoupled=True: AdamW (torch.optim.AdamW; trainers/vit.py:29, trainers/utils/optimizer.py:14-15).  no_decay: the
@@ -174,7 +179,7 @@ class FlatAdam:
                 _ptr(self.flat_p[k]), _ptr(b.flat), _ptr(self.m[k]), _ptr(self.v[k]), b.flat.numel(),
                 _ptr(self.seg[k]), _ptr(tab_d), _ptr(self.partials), self.partials.numel(),
                 clip, float(self.lr), float(b1), float(b2), float(self.eps), float(self.weight_decay),
-                3 if self.decoupled else 2, _ptr(self.norm) if k == 0 else _ptr(None),
+                (2 if self.TABLE_WD else 0) | (1 if self.decoupled else 0), _ptr(self.norm) if k == 0 else _ptr(None),
                 _ptr(self.flat_p16[k]) if self.flat_p16 else _ptr(None), stream)
             _lib.check(rc, "amk_adam_flat_step")
         red.mark_zeroed()

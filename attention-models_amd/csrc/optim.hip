@@ -89,11 +89,11 @@ __global__ __launch_bounds__(256) void adam_flat_kernel(AdamArgs a) {
     const float wdf = (a.decoupled & 2) ? t.w : (adamw ? a.lr * a.weight_decay : a.weight_decay);
 #define AMK_ADAM_ONE(f)                                                   \
     {                                                                     \
-      float gg = g.f * coef;                                              \
+      float gg = __fmul_rn(g.f, coef);   /* (rounded as clip_grad_norm_ leaves it, whatever gets fused below) */ \
       float pp = p.f;                                                     \
       if (wdf != 0.f) {                                                   \
         if (adamw) pp -= wdf * pp;                                        \
-        else gg += wdf * pp;                                              \
+        else gg = __fmaf_rn(wdf, pp, gg);   /* grad.add(param, alpha=wd) */ \
       }                                                                   \
       const float mm = m.f + omb1 * (gg - m.f);                           \
       const float vv = a.beta2 * v.f + omb2 * gg * gg;                    \

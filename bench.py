@@ -437,7 +437,7 @@ def secondary_main(args, world, rank, dev, n_ranks_seen):
             "config": {"workload": spec["workload"], "global_batch": batch * world, "batch_per_gpu": batch,
                        "parallelism": f"dp{world}", "final_loss": float(loss),
                        "gradient_bytes_per_allreduce": step.red.grads_nbytes(), "buckets": len(step.red.buckets),
-                       "static_unused_parameters": len(step.red.unused_parameters()) if step._graph is None else None}}),
+                       "static_unused_parameters": len(step.red.static_unused_parameters())}}),
             flush=True)
     if world > 1 or dist.is_initialized():
         dist.barrier()

@@ -94,7 +94,7 @@ def test_classifier_step_reduced_vit_moe(device):
         else:
             moved += int(not torch.equal(p, before[n]))
     assert moved >= sum(1 for n in before if "W_d" not in n) - 1     # (LambdaLR's first step has lr 0: two real updates follow)
-    unused = {id(p) for p in ts.red.unused_parameters()}
+    unused = {id(p) for p in ts.red.static_unused_parameters()}
     assert unused == {id(p) for n, p in model.named_parameters() if "W_d" in n}
 
 
@@ -234,7 +234,7 @@ def _moe_two_rank_worker(rank, world, port, out_dir):
                 ts._lr_arg = s
         torch.cuda.synchronize()
         torch.save(dict(params={n: p.detach().cpu().clone() for n, p in model.named_parameters()}, early=early,
-                        unused=[n for n, p in model.named_parameters() if any(p is q for q in ts.red.unused_parameters())]),
+                        unused=[n for n, p in model.named_parameters() if any(p is q for q in ts.red.static_unused_parameters())]),
                    os.path.join(out_dir, f"moe_w{world}_r{rank}.pt"))
     finally:
         if world > 1:
@@ -269,7 +269,7 @@ def test_vit_moe_config3_full_size_through_reducer_and_flat_adamw(device):
     model = ViTMoE(dim=1024, image_size=256, patch_size=32, n_heads=8, d_head=64, depth=6, n_experts=32, sel_experts=2,
                    dropout=0.0, num_classes=1000).to(device)
     ts = ClassifierTrainStep(model, lr=1e-4, warmup_steps=1, total_steps=100)
-    assert ts.red.grads_nbytes() > 960e6 and len(ts.red.buckets) >= 28
+    assert ts.red.grads_nbytes() > 960e6 and len(ts.red.buckets) >= 12
     wd0 = {n: p.detach().clone() for n, p in model.named_parameters() if "W_d" in n}
     g = torch.Generator().manual_seed(2)
     imgs = torch.randn(8, 3, 256, 256, generator=g).to(device)
@@ -281,7 +281,7 @@ def test_vit_moe_config3_full_size_through_reducer_and_flat_adamw(device):
         if "W_d" in n:
             assert torch.equal(p, wd0[n]), n
     assert any(not torch.equal(a, b) for a, b in zip(first, list(model.parameters())[:4]))
-    assert {id(p) for p in ts.red.unused_parameters()} == {id(p) for n, p in model.named_parameters() if "W_d" in n}
+    assert {id(p) for p in ts.red.static_unused_parameters()} == {id(p) for n, p in model.named_parameters() if "W_d" in n}
 
 
 def test_masked_token_step_frozen_vq(device):
