@@ -28,7 +28,20 @@ class GraphedStep:
                 fn(*self.static_inputs)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        kw = {}
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # a process group is alive: ProcessGroupNCCL's watchdog thread polls the events of collectives issued EARLIER
+            # (the warm-up steps) with hipEventQuery, which a capture in "global" mode forbids to every thread of the
+            # process ("operation not permitted when stream is capturing" -> the watchdog aborts the process; seen on
+            # MI355X with the 962 MB ViTMoE step).  So: let those collectives finish and the watchdog drop them, and
+            # capture in thread-local mode (only this thread's calls are policed; the launches of the autograd threads
+            # into the capturing streams are captured all the same).
+            import time
+
+            torch.cuda.synchronize()
+            time.sleep(0.5)
+            kw["capture_error_mode"] = "thread_local"
+        with torch.cuda.graph(self.graph, **kw):
             self.static_outputs = fn(*self.static_inputs)
 
     def replay(self, *inputs):

@@ -86,7 +86,7 @@ class SupervisedTrainStep:
     def __init__(self, model, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, no_decay=(), decoupled=True,
                  schedule="cosine_with_warmup", warmup_steps=0, total_steps=1, max_grad_norm=1.0, accum_steps=1,
                  autocast=None, capturable=False, bucket_bytes=32 << 20, fused_optimizer=None, direct_grads=None,
-                 communicate_when_alone=False):
+                 communicate_when_alone=False, overlap=True):
         self.model = model
         self.base_lr, self.schedule = float(lr), schedule
         self.warmup_steps, self.total_steps = int(warmup_steps), int(total_steps)
@@ -96,7 +96,7 @@ class SupervisedTrainStep:
         # communicate_when_alone: a world of one rank issues its (identity) RCCL all-reduces anyway -- how the one-GPU test
         # box exercises the collective path, eager and captured
         self.red = GradReducer([p for _, p in named], bucket_bytes, communicate_when_alone=communicate_when_alone,
-                               direct_grads=on_gpu if direct_grads is None else bool(direct_grads))
+                               overlap=overlap, direct_grads=on_gpu if direct_grads is None else bool(direct_grads))
         skip = [p for n, p in named if any(frag in n for frag in no_decay)]
         self.fused_optimizer = on_gpu if fused_optimizer is None else bool(fused_optimizer)
         if self.fused_optimizer:
@@ -248,7 +248,8 @@ class VQGANTrainStep:
     def __init__(self, model, discr, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.0,
                  adv_loss_weight=0.1, logit_laplace_weight=1.0, max_grad_norm=1.0,
                  warmup_steps=50000, decay_steps=100000, gp_lambda=10.0, bucket_bytes=32 << 20,
-                 share_forward=False, capturable=False, fused_optimizer=None, autocast=None, communicate_when_alone=False):
+                 share_forward=False, capturable=False, fused_optimizer=None, autocast=None, communicate_when_alone=False,
+                 overlap=True):
         self.model, self.discr = model, discr
         # autocast: None (f32, the parity mode) or a dtype (torch.bfloat16): the forward passes and losses of both phases
         # run inside torch.autocast as the reference's do (trainers/vitgqgan.py:149,168 `accelerator.autocast()`);
@@ -260,8 +261,11 @@ class VQGANTrainStep:
         fused = next(model.parameters()).is_cuda
         # direct_grads: the Linear layers' weight-gradient kernels write straight into the generator's gradient buckets (no
         # weight is shared between two such layers in ViTVQGAN); the discriminator's convolutions go through autograd
-        self.g_red = GradReducer(model.parameters(), bucket_bytes, direct_grads=fused, communicate_when_alone=communicate_when_alone)
-        self.d_red = GradReducer(discr.parameters(), bucket_bytes, communicate_when_alone=communicate_when_alone)
+        # overlap=False: all-reduces on the compute stream (see amk.dp.GradReducer: what a captured step with little
+        # gradient traffic wants)
+        self.g_red = GradReducer(model.parameters(), bucket_bytes, direct_grads=fused, communicate_when_alone=communicate_when_alone,
+                                 overlap=overlap)
+        self.d_red = GradReducer(discr.parameters(), bucket_bytes, communicate_when_alone=communicate_when_alone, overlap=overlap)
         # fused_optimizer (default on the GPU): amk.optim.FlatAdam -- clip + Adam + zeroing in two passes over the
         # reducer's flat buckets (csrc/optim.hip) instead of clip_grad_norm_ + Adam.step + zero_grad.
         # capturable=True: step counts and learning rate live on the device (FlatAdam(capturable=True), or torch's

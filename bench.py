@@ -55,7 +55,11 @@ def parse():
                     help="vqgan (default): the headline, BASELINE.json configs[2].  vit / vitmoe / muse: a SECONDARY line -- the "
                          "data-parallel classifier step of configs[1] / configs[3] (trainers/vit.py) or the masked-token decoder step "
                          "of configs[4] (trainers/muse.py) through the same reducer, optimizer and graph capture")
-    ap.add_argument("--autocast", default="none", choices=["none", "bf16"], help="--model vit|vitmoe|muse only")
+    ap.add_argument("--autocast", default="none", choices=["none", "bf16"],
+                    help="bf16: the reference's shipped precision (cfg/vitvqgan.yaml:73); makes the line a SECONDARY one (the headline is f32)")
+    ap.add_argument("--dp-overlap", default="auto", choices=["auto", "on", "off"],
+                    help="all-reduces on a side stream under backward (on) or on the compute stream (off).  auto: on, except for a "
+                         "graph-captured step with less than 256 MB of gradients (a forked graph is launched node by node by the host)")
     return ap.parse_args()
 
 
@@ -328,8 +332,9 @@ def dp_graph_ok(dev, world):
         cap = torch.cuda.Stream(device=dev)
         cap.wait_stream(torch.cuda.current_stream())
         graph = torch.cuda.CUDAGraph()
+        time.sleep(0.5)   # (the watchdog drops the finished warm-up collective: see amk/graphs.py)
         with torch.cuda.stream(cap):
-            with torch.cuda.graph(graph, stream=cap):
+            with torch.cuda.graph(graph, stream=cap, capture_error_mode="thread_local"):
                 buf.mul_(2.0)
                 ev = torch.cuda.Event()
                 ev.record(torch.cuda.current_stream())
@@ -365,6 +370,13 @@ SECONDARY = {
 }
 
 
+def _overlap(choice, graphed, communicating, model):
+    if choice != "auto":
+        return choice == "on"
+    nbytes = 4 * sum(p.numel() for p in model.parameters() if p.requires_grad)
+    return not (graphed and communicating and nbytes < (256 << 20))
+
+
 def secondary_main(args, world, rank, dev, n_ranks_seen):
     """--model vit | vitmoe | muse: the data-parallel single-model step (amk.train.ClassifierTrainStep /
     MaskedTokenTrainStep) -- a secondary line, never the headline."""
@@ -380,6 +392,7 @@ def secondary_main(args, world, rank, dev, n_ranks_seen):
     can_graph, graph_why = (False, "--no-graph") if args.no_graph else dp_graph_ok(dev, world)
     alone_rccl = os.environ.get("AMK_BENCH_RCCL_ALONE", "0") == "1"
     kw = dict(capturable=can_graph, autocast=amp, communicate_when_alone=alone_rccl, max_grad_norm=1.0)
+    overlap_arg = args.dp_overlap
     torch.manual_seed(0)
     g = torch.Generator().manual_seed(1234 + rank)
     if args.model == "muse":
@@ -387,6 +400,7 @@ def secondary_main(args, world, rank, dev, n_ranks_seen):
 
         vq = ViTVQGAN(VIT, CODEBOOK)
         model = MUSE(dim=1024, vq=vq, n_heads=16, d_head=64, depth=22, mult=6).to(dev)
+        kw["overlap"] = _overlap(overlap_arg, can_graph, world > 1 or alone_rccl, model)
         step = MaskedTokenTrainStep(model, lr=1e-4, weight_decay=0.0, warmup_steps=1000, **kw)
         data = (torch.randn(batch, 77, 768, generator=g).to(dev), torch.rand(batch, 3, 256, 256, generator=g).to(dev))
     else:
@@ -398,6 +412,7 @@ def secondary_main(args, world, rank, dev, n_ranks_seen):
         else:
             model = ViTMoE(dim=1024, image_size=256, patch_size=32, n_heads=8, d_head=64, depth=6, n_experts=32, sel_experts=2,
                            dropout=0.0, num_classes=1000).to(dev)
+        kw["overlap"] = _overlap(overlap_arg, can_graph, world > 1 or alone_rccl, model)
         step = ClassifierTrainStep(model, lr=1e-4, warmup_steps=1000, total_steps=100000, **kw)
         data = (torch.randn(batch, 3, 256, 256, generator=g).to(dev), torch.randint(0, 1000, (batch,), generator=g).to(dev))
     nparam = sum(p.numel() for p in step.red.params)
@@ -427,18 +442,19 @@ def secondary_main(args, world, rank, dev, n_ranks_seen):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": spec["metric"], "value": batch * world * args.steps / dt, "unit": "images/s", "n_gpus": world,
             "n_ranks_seen": n_ranks_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "host_enqueue_ms": t_host / args.steps * 1e3, "step_launch": graph, "graph_decision": graph_why,
+            "dp_allreduce": ("side stream, overlapped with backward" if step.red.overlap else "compute stream, at bucket completion")
+                            if not step.red.alone else None,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if amp is None else "bf16 (autocast)", "data": "synthetic N(0,1) images, random-init weights",
             "secondary": True,
             "config": {"workload": spec["workload"], "global_batch": batch * world, "batch_per_gpu": batch,
                        "parallelism": f"dp{world}", "final_loss": float(loss),
                        "gradient_bytes_per_allreduce": step.red.grads_nbytes(), "buckets": len(step.red.buckets),
-                       "static_unused_parameters": len(step.red.static_unused_parameters())}}),
-            flush=True)
+                       "static_unused_parameters": len(step.red.static_unused_parameters())}})
     if world > 1 or dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -463,8 +479,7 @@ def self_launch(args):
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
     out, _ = procs[0].communicate()
     rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
-    sys.stdout.flush()
+    os.write(REAL_STDOUT, out)
     if any(rcs):
         raise SystemExit(f"bench.py: rank exit codes {rcs}")
 
@@ -479,8 +494,23 @@ def latest_pmc_digest():
     return json.load(open(paths[-1])), os.path.relpath(paths[-1], ROOT)
 
 
+def emit(line):
+    """The ONE JSON line, on the process's real stdout."""
+    os.write(REAL_STDOUT, (json.dumps(line) + "\n").encode())
+
+
+REAL_STDOUT = 1
+
+
 def main():
+    global REAL_STDOUT
     args = parse()
+    # stdout carries the one JSON line and nothing else: native libraries write to fd 1 behind Python's back (RCCL prints
+    # a version banner there when a communicator is created), so fd 1 is pointed at stderr for the life of the process and
+    # the line goes to a duplicate of the original
+    sys.stdout.flush()
+    REAL_STDOUT = os.dup(1)
+    os.dup2(2, 1)
     # dmabuf IPC is what RCCL needs on this pool; set before the first HIP call, for BOTH launch modes (the driver's
     # torch.distributed.run launch never passes through self_launch)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -541,7 +571,13 @@ def main():
     # N ranks over RCCL: the same single replay, with the reducers' all-reduces (side stream) captured inside it -- after
     # a pre-flight that captures and replays one small all-reduce on every rank (dp_graph_ok); over gloo (rehearsal): eager
     use_graph, graph_why = (False, "--no-graph") if args.no_graph else dp_graph_ok(dev, world)
-    trainer = VQGANTrainStep(model, discr, capturable=use_graph, communicate_when_alone=alone_rccl)
+    communicating = world > 1 or alone_rccl
+    overlap = {"on": True, "off": False, "auto": not (use_graph and communicating)}[args.dp_overlap]
+    bf16 = args.autocast == "bf16"
+    if bf16:
+        args.no_kernels = args.no_variants = args.no_cpu_baseline = True
+    trainer = VQGANTrainStep(model, discr, capturable=use_graph, communicate_when_alone=alone_rccl, overlap=overlap,
+                             autocast=torch.bfloat16 if bf16 else None)
     g = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, VIT["img_size"], VIT["img_size"], generator=g).to(dev)
 
@@ -721,10 +757,12 @@ def main():
             "step_launch": ("one HIP-graph replay per step" + (" (RCCL all-reduces captured inside)" if world > 1 or alone_rccl else ""))
                            if use_graph else "eager",
             "graph_decision": graph_why,
+            "dp_allreduce": ("side stream, overlapped with backward" if overlap else "compute stream, at bucket completion") if communicating else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "bf16 (autocast)" if bf16 else "f32",
+            **({"secondary": True} if bf16 else {}),
             "data": "synthetic U[0,1) images, random-init weights",
             "config": {
                 "workload": "BASELINE.json configs[2]: ViTVQGAN dim=256 patch=8 img=256 depth=6+6 h=8 d=64 "
@@ -812,7 +850,7 @@ def main():
             line["kernels_agent"] = agent
         if cpu:
             line["cpu_baseline"] = cpu
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1 or dist.is_initialized():
         # teardown in a defined order: rank 0's post-headline work (kernel micro-benchmarks, the JSON line) is done
         # before any rank leaves the group -- the other ranks wait here instead of tearing RCCL down under it

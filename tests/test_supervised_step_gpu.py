@@ -106,11 +106,13 @@ def _rccl_world_of_one(device):
 
 
 @pytest.mark.timeout(600)
-def test_captured_dp_step_with_collectives_replays_like_eager(device):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_captured_dp_step_with_collectives_replays_like_eager(device, overlap):
     """The data-parallel step as ONE HIP-graph replay: RCCL all-reduces (issued from the autograd hooks on the reducer's side
     stream) are captured with the forward, backward, clip and AdamW.  World of one rank with communicate_when_alone=True:
     the collectives are real RCCL launches.  The replayed steps must equal the eager steps to the bits (reproducible
-    attention backward), on the reduced ViTMoE and on the GAN step of the headline."""
+    attention backward), on the reduced ViTMoE.  overlap=False: the all-reduces sit on the compute stream (a single-stream
+    graph: what bench.py captures for the ViT-VQGAN step, whose 90 MB of gradients do not need the overlap)."""
     from amk import ops
     from amk.models import ViTMoE
     from amk.train import ClassifierTrainStep
@@ -126,8 +128,8 @@ def test_captured_dp_step_with_collectives_replays_like_eager(device):
         for graphed in (False, True):
             model = copy.deepcopy(base)
             ts = ClassifierTrainStep(model, lr=1e-3, warmup_steps=2, total_steps=20, bucket_bytes=256 << 10, capturable=True,
-                                     communicate_when_alone=True)
-            assert not ts.red.alone and ts.red.avg_in_collective and len(ts.red.buckets) > 2
+                                     communicate_when_alone=True, overlap=overlap)
+            assert not ts.red.alone and ts.red.avg_in_collective and len(ts.red.buckets) > 2 and ts.red.overlap == overlap
             losses = []
             if graphed:
                 ts.capture(imgs, labels, warmup=2)         # two real steps, then the capture
