@@ -33,7 +33,7 @@ struct FusedGeom {
   static constexpr int NT = 64 * NW;          // threads
   static constexpr int KB = 32 * NW;          // keys per workgroup
   static constexpr int DS_STRIDE = KB + 4;    // dS tile row stride (floats): 16-B aligned rows, b128 row reads
-  static constexpr int LDS_FLOATS = 2 * TQ * LDS_STRIDE + KB * LDS_STRIDE + TQ * DS_STRIDE + 3 * TQ;
+  static constexpr int LDS_FLOATS = 2 * TQ * LDS_STRIDE + KB * LDS_STRIDE + TQ * DS_STRIDE + 4 * TQ;
   static constexpr int NBLK = 8 / NW;         // 16x16 dQ blocks per wave
   static constexpr int KPG = KB / 4;          // keys per k-group of the 16x16x4 product
 };
@@ -61,7 +61,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
   float* dSl = Kc + KB * LDS_STRIDE;          // [TQ][DS_STRIDE]   dS of the current tile
   float* Ms = dSl + TQ * DS_STRIDE;
   float* Ls = Ms + TQ;
-  float* Ds = Ls + TQ;
+  float* Ds = Ls + TQ;    // MINUS delta: the initial accumulator of the dP chain (dP - delta leaves the matrix pipe)
+  float* MLs = Ds + TQ;   // m + log2 l: P = exp2(S - MLs) in one subtraction where no fill can occur (plain tiles)
 
   const int tid = threadIdx.x;
   // wave-uniform by construction; readfirstlane tells the compiler (scalar registers, and no waterfall
@@ -181,7 +182,8 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
     if (tid < TQ) {  // LDS stores only
       Ms[tid] = row_ok ? ml_raw.x : INFINITY;
       Ls[tid] = row_ok ? 1.f / ml_raw.y : 0.f;
-      Ds[tid] = row_ok ? dl_raw : 0.f;
+      Ds[tid] = row_ok ? -dl_raw : 0.f;
+      MLs[tid] = row_ok ? ml_raw.x + __builtin_amdgcn_logf(ml_raw.y) : INFINITY;   // (v_log_f32 is log2)
     }
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -228,7 +230,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
     const int i0 = tile_of(t) * TQ;
 
     // ---- S and dP for the tile's 32 queries x this wave's 32 keys
-    f32x16 s = zero16(), dp = zero16();
+    // dP's chain starts from -delta of the register's query row: the subtraction of softmax's backward costs no VALU
+    f32x16 s = zero16(), dp;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float4 d4 = ld4(&Ds[8 * g + 4 * hf]);
+      dp[4 * g + 0] = d4.x; dp[4 * g + 1] = d4.y; dp[4 * g + 2] = d4.z; dp[4 * g + 3] = d4.w;
+    }
     {
       const float* qr = &Qs[ln * LDS_STRIDE + 32 * hf];
       const float* gr = &Gs[ln * LDS_STRIDE + 32 * hf];
@@ -260,15 +268,16 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
     if (plain) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float4 m4 = ld4(&Ms[8 * g + 4 * hf]);
-        const float4 l4 = ld4(&Ls[8 * g + 4 * hf]);
-        const float4 d4 = ld4(&Ds[8 * g + 4 * hf]);
+        // (no fill in this wave's columns, so every row has a live key here and m is a genuine score maximum: the
+        // normaliser folds into the exponent, P = exp2(S - (m + log2 l)); the two-constant form below is for rows whose
+        // m may be the fill value, where m + log2 l would swallow l)
+        const float4 ml4 = ld4(&MLs[8 * g + 4 * hf]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
-          const float pr = __builtin_amdgcn_exp2f(s[r] - f4(m4, e)) * f4(l4, e);
+          const float pr = __builtin_amdgcn_exp2f(s[r] - f4(ml4, e));
           s[r] = pr;
-          dp[r] = pr * (dp[r] - f4(d4, e));
+          dp[r] = pr * dp[r];
         }
       }
     } else {
@@ -283,7 +292,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
       for (int g = 0; g < 4; ++g) {
         const float4 m4 = ld4(&Ms[8 * g + 4 * hf]);
         const float4 l4 = ld4(&Ls[8 * g + 4 * hf]);
-        const float4 d4 = ld4(&Ds[8 * g + 4 * hf]);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int r = 4 * g + e;
@@ -291,7 +299,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
           const float tt = filled ? fillv : s[r];
           const float pr = __builtin_amdgcn_exp2f(tt - f4(m4, e)) * f4(l4, e);
           s[r] = pr;
-          dp[r] = filled ? 0.f : pr * (dp[r] - f4(d4, e));
+          dp[r] = filled ? 0.f : pr * dp[r];
         }
       }
     }

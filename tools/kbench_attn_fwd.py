@@ -19,6 +19,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--f32-only", action="store_true")
     a = ap.parse_args()
     from amk import ops
 
@@ -30,7 +31,7 @@ def main():
     qd, kd, vd = (t[0, 0].double().cpu() for t in (q, k, v))
     ref = torch.softmax(qd @ kd.t() * s, -1) @ vd
     fl = 4.0 * B * H * T * T * D
-    for mode in ("f32", "bf16x6"):
+    for mode in (("f32",) if a.f32_only else ("f32", "bf16x6")):
         ops.ATTENTION_FORWARD = mode
         o = ops.attention(q, k, v, s)
         err = float((o[0, 0].double().cpu() - ref).abs().max() / ref.abs().max())
