@@ -78,9 +78,9 @@ SIGNATURES = {
     "amk_gemm_f32_ws_bytes": (_L, [_c.POINTER(GemmDesc)]),
     "amk_gemm_f32": (_I, [_c.POINTER(GemmDesc), _P, _L, _P]),
     "amk_row_stats": (_I, [_P, _L, _I, _F, _P, _P, _P]),
-    "amk_attn_bf16_fwd": (_I, [_P] * 5 + [_I] * 5 + [_L] * 12 + [_F, _P]),
+    "amk_attn_bf16_fwd": (_I, [_P] * 7 + [_I] * 5 + [_L] * 12 + [_F, _P]),
     "amk_attn_bf16_bwd_ws_floats": (_L, [_I, _I, _I, _I]),
-    "amk_attn_bf16_bwd": (_I, [_P] * 10 + [_I] * 5 + [_L] * 24 + [_F, _P]),
+    "amk_attn_bf16_bwd": (_I, [_P] * 12 + [_I] * 5 + [_L] * 24 + [_F, _P]),
     "amk_swiglu_bf16_fwd": (_I, [_P, _L, _I, _P, _P]),
     "amk_swiglu_bf16_bwd": (_I, [_P, _P, _L, _I, _P, _P]),
     "amk_add_layernorm_mixed_fwd": (_I, [_P, _I, _P, _P, _P, _L, _I, _F, _P, _P, _P, _P, _P]),

@@ -304,9 +304,10 @@ class _AttnFusedKV(torch.autograd.Function):
         return dq2, dkv2, None, None, None, None, None
 
 
-# Mixed precision (the reference's shipped bf16 autocast): with bf16 projections coming in, no masks and head dim 64 the
-# core runs on the bf16-MFMA kernels of csrc/attn_bf16.hip (bf16 q / k / v / o and gradients, f32 scores, softmax and
-# statistics); AMK_ATTENTION_BF16=0 keeps the round-2 behaviour (inputs upcast, exact-f32 kernels).
+# Mixed precision (the reference's shipped bf16 autocast): with bf16 projections coming in and head dim 64 the core runs
+# on the bf16-MFMA kernels of csrc/attn_bf16.hip (bf16 q / k / v / o and gradients, f32 scores, softmax and statistics),
+# with or without key-padding / causal masks; AMK_ATTENTION_BF16=0 keeps the round-2 behaviour (inputs upcast, exact-f32
+# kernels).
 ATTENTION_BF16 = os.environ.get("AMK_ATTENTION_BF16", "1") == "1"
 
 
@@ -315,7 +316,8 @@ class _AttnFusedKVBF16(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type="cuda")
-    def forward(ctx, q2, kv2, H, scale):
+    def forward(ctx, q2, kv2, H, scale, key_mask=None, causal_mask=None):
+        """key_mask: uint8 (B, J), 1 = keep; causal_mask: uint8 (I, J), 1 = masked (see _mask_u8); or None."""
         B, I, _ = q2.shape
         J = kv2.shape[1]
         D = 64
@@ -325,18 +327,20 @@ class _AttnFusedKVBF16(torch.autograd.Function):
         stats = torch.empty((B, H, I, 2), device=q2.device, dtype=torch.float32)
         L = _lib.load()
         qs, kvs = (I * H * D, H * D, D), (J * 2 * H * D, 2 * H * D, D)
-        with _timed("attn_bf16_fwd_kernel"):
+        masked = key_mask is not None or causal_mask is not None
+        with _timed("attn_bf16_fwd_kernel<masked>" if masked else "attn_bf16_fwd_kernel"):
             rc = L.amk_attn_bf16_fwd(_ptr(q2), _ptr(kv2), ctypes.c_void_p(kv2.data_ptr() + 2 * H * D), _ptr(o2), _ptr(stats),
+                                     _ptr(key_mask), _ptr(causal_mask),
                                      B, H, I, J, D, *qs, *kvs, *kvs, *qs, float(scale), _stream())
         _lib.check(rc, "amk_attn_bf16_fwd")
-        ctx.save_for_backward(q2, kv2, o2, stats)
+        ctx.save_for_backward(q2, kv2, o2, stats, key_mask, causal_mask)
         ctx.cfg = (H, scale)
         return o2
 
     @staticmethod
     @_amp_bwd
     def backward(ctx, d_o2):
-        q2, kv2, o2, stats = ctx.saved_tensors
+        q2, kv2, o2, stats, key_mask, causal_mask = ctx.saved_tensors
         H, scale = ctx.cfg
         B, I, _ = q2.shape
         J = kv2.shape[1]
@@ -347,12 +351,14 @@ class _AttnFusedKVBF16(torch.autograd.Function):
         L = _lib.load()
         ws = torch.empty((L.amk_attn_bf16_bwd_ws_floats(B, H, I, J),), device=q2.device, dtype=torch.float32)
         qs, kvs = (I * H * D, H * D, D), (J * 2 * H * D, 2 * H * D, D)
-        with _timed("attn_bf16_bwd_kernel"):
+        masked = key_mask is not None or causal_mask is not None
+        with _timed("attn_bf16_bwd_kernel<masked>" if masked else "attn_bf16_bwd_kernel"):
             rc = L.amk_attn_bf16_bwd(_ptr(q2), _ptr(kv2), ctypes.c_void_p(kv2.data_ptr() + 2 * H * D), _ptr(o2), _ptr(stats), _ptr(d_o2),
                                      _ptr(dq2), _ptr(dkv2), ctypes.c_void_p(dkv2.data_ptr() + 2 * H * D), _ptr(ws),
+                                     _ptr(key_mask), _ptr(causal_mask),
                                      B, H, I, J, D, *qs, *kvs, *kvs, *qs, *qs, *qs, *kvs, *kvs, float(scale), _stream())
         _lib.check(rc, "amk_attn_bf16_bwd")
-        return dq2, dkv2, None, None
+        return dq2, dkv2, None, None, None, None
 
 
 def attention(q, k, v, scale, key_mask=None, causal_mask=None):
@@ -372,11 +378,10 @@ def attention_fused_kv(q2, kv2, num_heads, dim_head, scale, key_mask=None, causa
     """q2 (B,I,h*d), kv2 (B,J,2*h*d) -> (B,I,h*d); see _AttnFusedKV."""
     B, I, _ = q2.shape
     J = kv2.shape[1]
-    if (ATTENTION_BF16 and q2.dtype == torch.bfloat16 and kv2.dtype == torch.bfloat16 and q2.is_cuda and dim_head == 64
-            and key_mask is None and causal_mask is None):
-        return _AttnFusedKVBF16.apply(q2, kv2, num_heads, scale)
     km = _mask_u8(key_mask, (B, J), "context_mask")
     cm = _mask_u8(causal_mask, (I, J), "causal_mask")
+    if ATTENTION_BF16 and q2.dtype == torch.bfloat16 and kv2.dtype == torch.bfloat16 and q2.is_cuda and dim_head == 64:
+        return _AttnFusedKVBF16.apply(q2, kv2, num_heads, scale, km, cm)
     return _AttnFusedKV.apply(q2, kv2, km, cm, num_heads, dim_head, scale)
 
 

@@ -3,8 +3,13 @@
 // Under autocast the reference's q / kv projections and both einsums of models/softmax_attention.py:62-76 run in
 // bf16 and the softmax in f32; here q, k, v, o (and dO, dq, dk, dv) are bf16 tensors, the two contractions run on
 // v_mfma_f32_32x32x16_bf16 with f32 accumulators, scores / softmax / statistics stay f32 (the reference rounds the
-// scores to bf16 before its softmax; this kernel does not).  Head dim 64, no masks: masked calls, other head dims and
-// f32 tensors take the exact-f32 kernels.
+// scores to bf16 before its softmax; this kernel does not).  Head dim 64; other head dims and f32 tensors take the
+// exact-f32 kernels.  Key-padding and causal masks (models/softmax_attention.py:65-71: masked_fill(-1e9) on the scaled
+// scores, True = keep for context_mask, True = masked for causal_mask) are template variants <MASKED> of both kernels:
+// the unmasked loops are unchanged; the masked ones put -1e9 / scale in place of a raw score (so that c2 * fill is the
+// reference's -1e9 in the log2 domain), form the exponent as (s * c2) - (m * c2) with two rounded operations -- exactly 0
+// where s is the row maximum, also at 1.4e9, so a fully masked row keeps the reference's uniform weights -- and keep the
+// normaliser 1 / l as its own factor in the backward (m + log2 l would swallow l on such a row).
 //
 // Forward: the structure of attn_fwd.hip -- 4 waves x 32 queries, query on the lane, S^T = K Q^T, the S^T
 // accumulators packed to bf16 are the B operand of O^T += V^T P^T -- with
@@ -37,7 +42,8 @@ struct Params {
   const __bf16 *q, *k, *v, *o, *d_o;
   __bf16 *out, *dq, *dk, *dv;
   float* stats;        // (B, H, I, 2): row max in the log2 domain, row sum
-  float* delta;        // (B, H, I) x 2: the backward row constants {-(m + log2 l) / c2, -rowsum(dO * O)}
+  float* delta;        // (B, H, I) x 4: the backward row constants {-(m + log2 l) / c2, -rowsum(dO * O), m, 1 / l}
+  const uint8_t *key_mask, *causal_mask;   // (B, J) 1 = keep; (I, J) 1 = masked; or null
   float* dq_part;      // (nkblk, B, I, H, 64) f32
   int B, H, I, J;
   Strides qs, ks, vs, os, dos, dqs, dks, dvs;
@@ -91,10 +97,11 @@ __device__ __forceinline__ void lds_barrier_bf() {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int DUMMY>
+template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
   __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * KSTR];
   __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * TSTR];
+  __shared__ __attribute__((aligned(16))) float Kfill[MASKED ? 64 : 4];   // MASKED: per key of the tile 0 keep / fill / -inf past J
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
   const int qb = wg % p.nqblk, bh = wg / p.nqblk;
@@ -129,11 +136,20 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
   }
   const int kstep = (int)(64 * p.ks.st * 2), vstep = (int)(64 * p.vs.st * 2);
   float4 kst[2], vst[2];
+  const float fill_raw = -1.0e9f / p.scale;   // masked_fill(-1e9) acts on the SCALED scores; s here is the raw q . k
+  const uint8_t* kmrow = MASKED && p.key_mask ? p.key_mask + (int64_t)b * p.J : nullptr;
+  const uint8_t* cmrow = MASKED && p.causal_mask ? p.causal_mask + (int64_t)min(qi, p.I - 1) * p.J : nullptr;
+  float fillst = 0.f;
   auto prefetch = [&](int t) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       kst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(k_rsrc, koff[i] + t * kstep, 0, 0));
       vst[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(v_rsrc, voff[i] + t * vstep, 0, 0));
+    }
+    if (MASKED) {   // (all threads, clamped address: no branch around the load)
+      const int j = t * 64 + (tid & 63);
+      const uint8_t keep = kmrow ? kmrow[min(j, p.J - 1)] : (uint8_t)1;
+      fillst = j >= p.J ? -INFINITY : (keep ? 0.f : fill_raw);
     }
   };
   auto commit = [&]() {
@@ -142,6 +158,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
       *reinterpret_cast<float4*>(&Ks[(srow + 32 * i) * KSTR + sch]) = kst[i];
       *reinterpret_cast<float4*>(&Vs[(srow + 32 * i) * TSTR + sch]) = vst[i];
     }
+    if (MASKED) Kfill[tid & 63] = fillst;   // (four waves write the same 64 values)
   };
   const float c2 = p.scale * AMK_LOG2E;
   f32x16 o0 = zero16(), o1 = zero16();
@@ -164,8 +181,31 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
       s0 = mfmab(ka, qf[c], s0);
       s1 = mfmab(kb, qf[c], s1);
     }
-    // keys beyond the sequence (the last tile only): weight 0
-    if (j0 + 64 > p.J) {
+    if (MASKED) {
+      // fills: per key of the tile from LDS; the causal bytes of this lane's query row for its 2 x 16 keys
+      unsigned cb0 = 0, cb1 = 0;
+      if (cmrow) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ja = j0 + acc_row(r, hf);
+          cb0 |= (cmrow[min(ja, p.J - 1)] ? 1u : 0u) << r;
+          cb1 |= (cmrow[min(ja + 32, p.J - 1)] ? 1u : 0u) << r;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float4 f0 = *reinterpret_cast<const float4*>(&Kfill[8 * g + 4 * hf]);
+        const float4 f1 = *reinterpret_cast<const float4*>(&Kfill[32 + 8 * g + 4 * hf]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const float fa = amk_attn::f4(f0, e), fb = amk_attn::f4(f1, e);
+          float t0 = ((cb0 >> r) & 1u) ? fill_raw : s0[r], t1 = ((cb1 >> r) & 1u) ? fill_raw : s1[r];
+          s0[r] = fa == 0.f ? t0 : fa;     // (key-padding fill and the -inf past the sequence win over the causal fill: same value or -inf)
+          s1[r] = fb == 0.f ? t1 : fb;
+        }
+      }
+    } else if (j0 + 64 > p.J) {   // keys beyond the sequence (the last tile only): weight 0
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int ja = j0 + acc_row(r, hf);
@@ -178,18 +218,20 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
     for (int r = 1; r < 16; ++r) mx = vmax(mx, vmax(s0[r], s1[r], p.pinf), p.pinf);
     mx = vmax(mx, __shfl_xor(mx, 32, 64), p.pinf);
     const float m_new = vmax(m_run, mx, p.pinf);
-    const float mc = m_new * c2;
+    const float mc = __fmul_rn(m_new, c2);
     float lsum = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float p0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -mc));
-      const float p1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -mc));
+      // MASKED: two rounded operations, so that s == m gives exactly 0 at any magnitude (a fused multiply-add leaves the
+      // rounding error of m * c2, +-64 at the fill value's 1.4e9)
+      const float p0 = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(s0[r], c2), mc) : __builtin_fmaf(s0[r], c2, -mc));
+      const float p1 = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(s1[r], c2), mc) : __builtin_fmaf(s1[r], c2, -mc));
       s0[r] = p0;
       s1[r] = p1;
       lsum += p0 + p1;
     }
     if (__any(m_new != m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+      const float alpha = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(m_run, c2), mc) : (m_run - m_new) * c2);
       l_run *= alpha;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
@@ -221,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
     }
     if (hf == 0) {
       float* sp = p.stats + (((int64_t)b * p.H + h) * p.I + qi) * 2;
-      sp[0] = m_run * c2;   // log2 domain, as the f32 kernels store it
+      sp[0] = __fmul_rn(m_run, c2);   // log2 domain, as the f32 kernels store it
       sp[1] = l_tot;
     }
   }
@@ -248,7 +290,7 @@ __global__ __launch_bounds__(256) void attn_bf16_delta_kernel(Params p) {
     // P = exp2(c2 S') comes out normalised) and dP' = dO.v - delta
     const float m = p.stats[2 * row], l = p.stats[2 * row + 1];
     const float c2 = p.scale * AMK_LOG2E;
-    reinterpret_cast<float2*>(p.delta)[row] = make_float2(-(m + __builtin_log2f(l)) / c2, -s);
+    reinterpret_cast<float4*>(p.delta)[row] = make_float4(-(m + __builtin_log2f(l)) / c2, -s, m, 1.f / l);
   }
 }
 
@@ -269,13 +311,14 @@ __device__ __forceinline__ bf16x8 tr_frag16(const __bf16* img, int stride, int r
   return cat4(tr_read(a), tr_read(a + 4 * stride));
 }
 
+template <bool MASKED, bool CAUSAL>
 __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   __bf16* Kt = reinterpret_cast<__bf16*>(smem_raw);                 // [256 keys][TSTR]
   __bf16* dSs = Kt + BKEYS * TSTR;                                  // 2 x [256 keys][DSTR]
   __bf16* tiles = dSs + 2 * BKEYS * DSTR;                           // 2 stages x {Qrow, Qtr, dOrow, dOtr}
   constexpr int STG = 2 * (32 * KSTR + 32 * TSTR);
-  float* stat = reinterpret_cast<float*>(tiles + 2 * STG);          // 2 stages x {-(m + log2 l) / c2, -delta} x 32
+  float* stat = reinterpret_cast<float*>(tiles + 2 * STG);          // 2 stages x {-(m + log2 l) / c2, -delta, m, 1 / l} x 32
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   const int wg = xcd_remap(blockIdx.x, gridDim.x);
@@ -315,11 +358,19 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   const int64_t tst = isq ? p.qs.st : p.dos.st;
   const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tbase, 0, (int)(((int64_t)(p.I - 1) * tst + 64) * 2), 0x00020000);
   const int toff = (int)(((int64_t)prow * tst + pch) * 2), tstep = (int)(32 * tst * 2);
-  const float2* rcp = reinterpret_cast<const float2*>(p.delta) + (int64_t)bh * p.I;
+  const float4* rcp = reinterpret_cast<const float4*>(p.delta) + (int64_t)bh * p.I;
   float4 piece[2];                        // two tiles in flight (a tile is ~1 us of work, a load up to 2 us away)
-  float2 st_rc[2] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f)};
+  float4 st_rc[2] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   const int ntile = (p.I + 31) / 32;
-  const __amdgpu_buffer_rsrc_t rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rcp, 0, p.I * 8, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rcp, 0, p.I * 16, 0x00020000);
+  // MASKED: this lane's key is filled for every query (key-padding mask); the causal bytes of its column come per tile
+  const float fill_raw = -1.0e9f / p.scale;
+  const bool kfilled = MASKED && p.key_mask && p.key_mask[(int64_t)b * p.J + min(key, p.J - 1)] == 0;
+  // (through a buffer descriptor: 32-bit offsets, rows past I clamped -- the causal mask is (I, J) bytes, I * J < 2^31)
+  const bool has_causal = CAUSAL;
+  const __amdgpu_buffer_rsrc_t cm_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(has_causal ? p.causal_mask : (const uint8_t*)p.delta), 0,
+                                                                           has_causal ? p.I * p.J : 0, 0x00020000);
+  const int cm_key = min(key, p.J - 1);
   // No branch around a memory instruction anywhere in the tile loop (every thread requests the row constants, rows
   // past the sequence at a clamped address; dQ leaves through a range-checked descriptor): behind such a branch the
   // compiler's waits stop counting and every wait drains everything in flight -- the tile's dQ stores included.
@@ -327,7 +378,11 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
     piece[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(t_rsrc, toff + t * tstep, 0, 0));
     const int i = t * 32 + (tid & 31);
     // rows past the sequence read zeros: P = exp2(0) = 1 there, next to dO = 0 and q = 0 rows: dV, dK get nothing, dS = 0
-    st_rc[slot] = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rc_rsrc, i * 8, 0, 0));
+    if (MASKED) st_rc[slot] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rc_rsrc, i * 16, 0, 0));
+    else {
+      const float2 two = __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rc_rsrc, i * 16, 0, 0));
+      st_rc[slot].x = two.x; st_rc[slot].y = two.y;
+    }
   };
   auto commit = [&](int stage, int slot) {
     __bf16* base = tiles + stage * STG + (isq ? 0 : 32 * KSTR + 32 * TSTR);
@@ -335,8 +390,9 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
     *reinterpret_cast<float4*>(&base[32 * KSTR + prow * TSTR + pch]) = piece[slot];      // transposed-read image
     {   // every thread writes the constants of row tid & 31 (sixteen copies of the same value): were it one wave only, the
         // compiler would move the request under that condition -- a branch around a memory instruction again
-      float* sb = stat + stage * 64;
+      float* sb = stat + stage * 128;
       sb[tid & 31] = st_rc[slot].x; sb[32 + (tid & 31)] = st_rc[slot].y;
+      if (MASKED) { sb[64 + (tid & 31)] = st_rc[slot].z; sb[96 + (tid & 31)] = st_rc[slot].w; }
     }
   };
   const float c2 = p.scale * AMK_LOG2E;
@@ -351,16 +407,22 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   // dQ: wave w owns the 16 x 16 block (queries 16 (w & 1), dims 16 (w >> 1)) of every tile, so its K operands -- the
   // same for every tile -- stay in registers
   const int qblk = wave & 1, dblk = wave >> 1;
-  bf16x8 kq[BKEYS / 32];
+  // (MASKED: 32 registers the mask logic needs more -- there the operands are re-read from LDS per tile)
+  bf16x8 kq[MASKED ? 1 : BKEYS / 32];
+  if (!MASKED) {
 #pragma unroll
-  for (int ks = 0; ks < BKEYS / 32; ++ks) kq[ks] = tr_frag16(Kt, TSTR, 32 * ks, 16 * dblk, lane);
+    for (int ks = 0; ks < BKEYS / 32; ++ks) kq[ks] = tr_frag16(Kt, TSTR, 32 * ks, 16 * dblk, lane);
+  }
   const __amdgpu_buffer_rsrc_t dq_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)dqp, 0, (int)(((int64_t)(p.I - 1) * p.H * 64 + 64) * 4), 0x00020000);
   auto dq_tile = [&](int tt) {
     const __bf16* img = dSs + (tt & 1) * BKEYS * DSTR;
     // the dQ^T block (dims x queries), so that a lane ends with four consecutive dims of ONE query: a 16-byte store
     f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+    int kofs = 0;
+    if (MASKED) asm volatile("" : "+v"(kofs));   // (opaque: keeps the compiler from hoisting the K reads out of the tile loop, back into 32 registers)
 #pragma unroll
-    for (int ks = 0; ks < BKEYS / 32; ++ks) acc = mfma16(kq[ks], tr_frag16(img, DSTR, 32 * ks, 16 * qblk, lane), acc);
+    for (int ks = 0; ks < BKEYS / 32; ++ks)
+      acc = mfma16(MASKED ? tr_frag16(Kt + kofs, TSTR, 32 * ks, 16 * dblk, lane) : kq[MASKED ? 0 : ks], tr_frag16(img, DSTR, 32 * ks, 16 * qblk, lane), acc);
     const int i = tt * 32 + 16 * qblk + (lane & 15);   // (tile -1 and rows past the sequence: outside the descriptor, dropped)
     const float4 o = make_float4(acc[0] * p.scale, acc[1] * p.scale, acc[2] * p.scale, acc[3] * p.scale);
     if (!(A16_ABLATE & 1))
@@ -373,16 +435,26 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
     const __bf16* Qtr = Qrow + 32 * KSTR;
     const __bf16* dOrow = Qtr + 32 * TSTR;
     const __bf16* dOtr = dOrow + 32 * KSTR;
-    const float* sb = stat + sg * 64;
+    const float* sb = stat + sg * 128;
     // ---- S' = Q K^T - lse / c2, dP' = dO V^T - delta: rows = queries (registers r <-> rows 8 g + 4 half + e of the
     //      tile), columns = keys (this lane's key); the row constants are the chains' initial accumulators
     f32x16 s, dp;
+    unsigned cbits = 0;   // MASKED: bit r = the causal mask fills (query of register r, this lane's key)
+    if (CAUSAL) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        cbits |= (__builtin_amdgcn_raw_buffer_load_b8(cm_rsrc, min(32 * t + acc_row(r, hf), p.I - 1) * p.J + cm_key, 0, 0) ? 1u : 0u) << r;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const float4 a4 = *reinterpret_cast<const float4*>(&sb[8 * g + 4 * hf]);
       const float4 d4 = *reinterpret_cast<const float4*>(&sb[32 + 8 * g + 4 * hf]);
-      s[4 * g] = a4.x; s[4 * g + 1] = a4.y; s[4 * g + 2] = a4.z; s[4 * g + 3] = a4.w;
       dp[4 * g] = d4.x; dp[4 * g + 1] = d4.y; dp[4 * g + 2] = d4.z; dp[4 * g + 3] = d4.w;
+      if (MASKED) {   // raw scores: the fill replaces them below
+        s[4 * g] = 0.f; s[4 * g + 1] = 0.f; s[4 * g + 2] = 0.f; s[4 * g + 3] = 0.f;
+      } else {
+        const float4 a4 = *reinterpret_cast<const float4*>(&sb[8 * g + 4 * hf]);
+        s[4 * g] = a4.x; s[4 * g + 1] = a4.y; s[4 * g + 2] = a4.z; s[4 * g + 3] = a4.w;
+      }
     }
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
@@ -395,12 +467,31 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
     //      S / dP chains in the matrix pipe, so that it runs under the exp work below
     if (!(A16_ABLATE & 2)) dq_tile(t - 1);   // (t = 0: an image nobody wrote, rows -32..-1: every store is dropped)
     // ---- P = exp2(c2 S'), dS / scale = P dP' (the scale goes onto dK and dQ where they are stored)
+    if (MASKED) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      float pr = (A16_ABLATE & 8) ? s[r] : __builtin_amdgcn_exp2f(s[r] * c2);
-      if (tail_keys) pr = kvalid ? pr : 0.f;
-      s[r] = pr;
-      dp[r] *= pr;
+      for (int g = 0; g < 4; ++g) {
+        const float4 m4 = *reinterpret_cast<const float4*>(&sb[64 + 8 * g + 4 * hf]);
+        const float4 l4 = *reinterpret_cast<const float4*>(&sb[96 + 8 * g + 4 * hf]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int r = 4 * g + e;
+          const bool filled = kfilled || ((cbits >> r) & 1u);
+          const float tt = filled ? fill_raw : s[r];
+          // (s * c2) - m with two rounded operations, as the forward formed it: exactly 0 where the fill is the row maximum
+          float pr = __builtin_amdgcn_exp2f(__fsub_rn(__fmul_rn(tt, c2), amk_attn::f4(m4, e))) * amk_attn::f4(l4, e);
+          pr = kvalid ? pr : 0.f;
+          s[r] = pr;                                 // a filled position still has its weight in P (dV), but passes no gradient
+          dp[r] = filled ? 0.f : dp[r] * pr;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float pr = (A16_ABLATE & 8) ? s[r] : __builtin_amdgcn_exp2f(s[r] * c2);
+        if (tail_keys) pr = kvalid ? pr : 0.f;
+        s[r] = pr;
+        dp[r] *= pr;
+      }
     }
     // ---- dS^T image for dQ: this lane's key row, its 16 queries as four 8-byte pieces (image t & 1: the dQ product
     //      of tile t runs in the NEXT iteration, beside that tile's S / dP work, so one barrier per tile is enough)
@@ -481,6 +572,7 @@ static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) =
 static bool st_ok(const Strides& s) { return s.sb % 8 == 0 && s.st % 8 == 0 && s.sh % 8 == 0; }
 
 extern "C" int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, float* stats,
+                                 const uint8_t* key_mask, const uint8_t* causal_mask,
                                  int B, int H, int I, int J, int Dh,
                                  int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
                                  int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
@@ -490,6 +582,7 @@ extern "C" int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, vo
   AMK_CHECK_SUPPORTED(Dh == 64, "amk_attn_bf16_fwd: head dim %d not supported (64)", Dh);
   Params p = {};
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.out = (__bf16*)o; p.stats = stats;
+  p.key_mask = key_mask; p.causal_mask = causal_mask;
   p.B = B; p.H = H; p.I = I; p.J = J;
   p.qs = {q_sb, q_st, q_sh}; p.ks = {k_sb, k_st, k_sh}; p.vs = {v_sb, v_st, v_sh}; p.os = {o_sb, o_st, o_sh};
   p.scale = scale; p.pinf = INFINITY;
@@ -500,7 +593,10 @@ extern "C" int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, vo
   AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_bf16_fwd: grid too large");
   AMK_CHECK_SUPPORTED(((int64_t)J + 64) * k_st * 2 < (1ll << 31) && ((int64_t)J + 64) * v_st * 2 < (1ll << 31),
                       "amk_attn_bf16_fwd: one (batch, head) K/V slab must span < 2 GiB");
-  hipLaunchKernelGGL(attn_bf16_fwd_kernel<0>, dim3((unsigned)nwg), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  if (key_mask || causal_mask)
+    hipLaunchKernelGGL(attn_bf16_fwd_kernel<true>, dim3((unsigned)nwg), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  else
+    hipLaunchKernelGGL(attn_bf16_fwd_kernel<false>, dim3((unsigned)nwg), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   AMK_CHECK_LAUNCH("amk_attn_bf16_fwd");
   return AMK_OK;
 }
@@ -508,11 +604,12 @@ extern "C" int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, vo
 extern "C" int64_t amk_attn_bf16_bwd_ws_floats(int B, int H, int I, int J) {
   if (B <= 0 || H <= 0 || I <= 0 || J <= 0) return 0;
   const int64_t nkblk = (J + BKEYS - 1) / BKEYS;
-  return ((2 * (int64_t)B * H * I + 3) & ~3ll) + nkblk * B * I * H * 64;   // row constants {-(lse)/c2, -delta} + dQ partials
+  return 4 * (int64_t)B * H * I + nkblk * B * I * H * 64;   // four row constants per query + dQ partials
 }
 
 extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const float* stats, const void* d_o,
                                  void* dq, void* dk, void* dv, float* ws,
+                                 const uint8_t* key_mask, const uint8_t* causal_mask,
                                  int B, int H, int I, int J, int Dh,
                                  int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
                                  int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
@@ -526,13 +623,14 @@ extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, co
   p.q = (const __bf16*)q; p.k = (const __bf16*)k; p.v = (const __bf16*)v; p.o = (const __bf16*)o; p.d_o = (const __bf16*)d_o;
   p.dq = (__bf16*)dq; p.dk = (__bf16*)dk; p.dv = (__bf16*)dv;
   p.stats = const_cast<float*>(stats);
+  p.key_mask = key_mask; p.causal_mask = causal_mask;
   p.B = B; p.H = H; p.I = I; p.J = J;
   p.qs = {q_sb, q_st, q_sh}; p.ks = {k_sb, k_st, k_sh}; p.vs = {v_sb, v_st, v_sh}; p.os = {o_sb, o_st, o_sh};
   p.dos = {do_sb, do_st, do_sh}; p.dqs = {dq_sb, dq_st, dq_sh}; p.dks = {dk_sb, dk_st, dk_sh}; p.dvs = {dv_sb, dv_st, dv_sh};
   p.scale = scale; p.pinf = INFINITY;
   p.nkblk = (J + BKEYS - 1) / BKEYS;
   p.delta = ws;
-  p.dq_part = ws + ((2 * (int64_t)B * H * I + 3) & ~3ll);
+  p.dq_part = ws + 4 * (int64_t)B * H * I;
   AMK_CHECK_ARG(al16(q) && al16(k) && al16(v) && al16(o) && al16(d_o) && al16(dq) && al16(dk) && al16(dv) && al16(p.dq_part) &&
                     st_ok(p.qs) && st_ok(p.ks) && st_ok(p.vs) && st_ok(p.os) && st_ok(p.dos) && st_ok(p.dqs) && st_ok(p.dks) && st_ok(p.dvs),
                 "amk_attn_bf16_bwd: pointers must be 16-byte aligned and strides multiples of 8 elements");
@@ -544,16 +642,20 @@ extern "C" int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, co
   hipLaunchKernelGGL(attn_bf16_delta_kernel, dim3((unsigned)((rows + 15) / 16)), dim3(256), 0, st, p);
   const int64_t nwg = (int64_t)B * H * p.nkblk;
   AMK_CHECK_SUPPORTED(nwg < (1ll << 31), "amk_attn_bf16_bwd: grid too large");
-  constexpr size_t lds = (size_t)(BKEYS * TSTR + 2 * BKEYS * DSTR + 4 * (32 * KSTR + 32 * TSTR)) * 2 + 2 * 64 * 4;
+  constexpr size_t lds = (size_t)(BKEYS * TSTR + 2 * BKEYS * DSTR + 4 * (32 * KSTR + 32 * TSTR)) * 2 + 2 * 128 * 4;
   static bool attr_set[64] = {};   // per device ordinal (the opt-in to > 64 KiB of dynamic LDS is per device)
   int dev_id = 0;
   AMK_CHECK_ARG(hipGetDevice(&dev_id) == hipSuccess && dev_id >= 0 && dev_id < 64, "amk_attn_bf16_bwd: no current device");
   if (!attr_set[dev_id]) {
-    AMK_CHECK_SUPPORTED(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
+    AMK_CHECK_SUPPORTED(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess &&
+                        hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bf16_bwd_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess,
                         "amk_attn_bf16_bwd: the device refused %zu bytes of dynamic LDS", lds);
     attr_set[dev_id] = true;
   }
-  hipLaunchKernelGGL(attn_bf16_bwd_kernel, dim3((unsigned)nwg), dim3(64 * BW), lds, st, p);
+  if (causal_mask) hipLaunchKernelGGL((attn_bf16_bwd_kernel<true, true>), dim3((unsigned)nwg), dim3(64 * BW), lds, st, p);
+  else if (key_mask) hipLaunchKernelGGL((attn_bf16_bwd_kernel<true, false>), dim3((unsigned)nwg), dim3(64 * BW), lds, st, p);
+  else hipLaunchKernelGGL((attn_bf16_bwd_kernel<false, false>), dim3((unsigned)nwg), dim3(64 * BW), lds, st, p);
   const int64_t n4 = (int64_t)B * I * H * 16;
   hipLaunchKernelGGL(attn_bf16_dq_reduce_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, p);
   AMK_CHECK_LAUNCH("amk_attn_bf16_bwd");

@@ -530,11 +530,15 @@ int amk_row_stats(const float* x, int64_t M, int D, float eps, float* mean, floa
  * models/softmax_attention.py:62-76 under bf16 autocast -- projections and both einsums in bf16, softmax in f32).
  * q, k, v, o, d_o, dq, dk, dv are bf16 (2-byte elements, strides in ELEMENTS, multiples of 8, 16-byte aligned);
  * contractions on v_mfma_f32_32x32x16_bf16 with f32 accumulation; scores, softmax and stats (B,H,I,2) are f32 as in
- * amk_attn_fwd.  Head dim 64, no masks (masked calls use the f32 entry points).
- * Backward: ws = amk_attn_bf16_bwd_ws_floats(B,H,I,J) floats (row sums of dO*O and per-key-block dq partials, summed
- * in key-block order by a second launch: no atomics, bitwise reproducible).
+ * amk_attn_fwd.  Head dim 64.  key_mask (B, J) 1 = keep and causal_mask (I, J) 1 = masked, bytes, either may be NULL:
+ * the masked_fill(-1e9) semantics of amk_attn_fwd (models/softmax_attention.py:65-71; a fully masked row keeps uniform
+ * weights), as template variants of the same kernels -- what Muse's padded text prompts (models/muse.py:88-96) and every
+ * masked call under the reference's autocast need.
+ * Backward: ws = amk_attn_bf16_bwd_ws_floats(B,H,I,J) floats (four row constants per query and per-key-block dq
+ * partials, summed in key-block order by a second launch: no atomics, bitwise reproducible).
  * -------------------------------------------------------------------------- */
 int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, float* stats,
+                      const uint8_t* key_mask, const uint8_t* causal_mask,
                       int B, int H, int I, int J, int D,
                       int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
                       int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,
@@ -542,6 +546,7 @@ int amk_attn_bf16_fwd(const void* q, const void* k, const void* v, void* o, floa
 int64_t amk_attn_bf16_bwd_ws_floats(int B, int H, int I, int J);
 int amk_attn_bf16_bwd(const void* q, const void* k, const void* v, const void* o, const float* stats, const void* d_o,
                       void* dq, void* dk, void* dv, float* ws,
+                      const uint8_t* key_mask, const uint8_t* causal_mask,
                       int B, int H, int I, int J, int D,
                       int64_t q_sb, int64_t q_st, int64_t q_sh, int64_t k_sb, int64_t k_st, int64_t k_sh,
                       int64_t v_sb, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_st, int64_t o_sh,

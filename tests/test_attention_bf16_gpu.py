@@ -52,8 +52,70 @@ def test_bf16_core_forward_backward(device, B, H, I, J):
     assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2)
 
 
+def _masked_ref(q, k, v, scale, key_mask, causal_mask):
+    """models/softmax_attention.py:62-76 in f32 on (B,H,T,D) tensors: masked_fill(-1e9), context_mask True = keep,
+    causal_mask True = masked."""
+    s = torch.einsum("bhid,bhjd->bhij", q, k) * scale
+    if key_mask is not None:
+        s = s.masked_fill(~key_mask[:, None, None, :], -1e9)
+    if causal_mask is not None:
+        s = s.masked_fill(causal_mask[None, None], -1e9)
+    return torch.einsum("bhij,bhjd->bhid", torch.softmax(s, -1), v)
+
+
+@pytest.mark.parametrize("B,H,I,J,kind", [(2, 2, 64, 64, "key"), (2, 3, 100, 77, "key"), (1, 2, 130, 130, "causal"),
+                                           (2, 2, 96, 300, "both"), (1, 1, 40, 70, "dead"), (2, 8, 1024, 77, "key"),
+                                           (1, 4, 512, 512, "causal")])
+def test_bf16_core_with_masks(device, B, H, I, J, kind):
+    """The <MASKED> variants of the bf16 kernels against an f32 computation on the bf16-rounded operands: key-padding
+    mask (the Muse text prompt: I 1024 x J 77), causal mask, both, and rows whose every key is masked (uniform weights,
+    as masked_fill(-1e9) gives them).  The launches are the bf16 kernels (asserted by name), not the f32 ones on upcasts."""
+    from amk import ops
+
+    D = 64
+    g = torch.Generator().manual_seed(B * 1000 + I + J)
+    q2 = seeded((B, I, H * D), 1).bfloat16()
+    kv2 = seeded((B, J, 2 * H * D), 2).bfloat16()
+    cot = seeded((B, I, H * D), 3).bfloat16()
+    key_mask = causal = None
+    if kind in ("key", "both", "dead"):
+        key_mask = torch.rand(B, J, generator=g) > 0.3
+        key_mask[:, 0] = True
+        if kind == "dead":
+            key_mask[0] = False                       # every key of batch 0 masked: uniform softmax over all J
+    if kind in ("causal", "both"):
+        causal = torch.ones(I, J, dtype=torch.bool).triu(1)
+    qr, kvr = q2.float().requires_grad_(True), kv2.float().requires_grad_(True)
+    q = qr.view(B, I, H, D).permute(0, 2, 1, 3)
+    kv = kvr.view(B, J, 2, H, D)
+    o_ref = _masked_ref(q, kv[:, :, 0].permute(0, 2, 1, 3), kv[:, :, 1].permute(0, 2, 1, 3), D ** -0.5, key_mask, causal)
+    o_ref2 = o_ref.permute(0, 2, 1, 3).reshape(B, I, H * D)
+    gq, gkv = torch.autograd.grad((o_ref2 * cot.float()).sum(), [qr, kvr])
+
+    qd, kvd = q2.to(device).requires_grad_(True), kv2.to(device).requires_grad_(True)
+    km = key_mask.to(device) if key_mask is not None else None
+    cm = causal.to(device) if causal is not None else None
+    ops.KERNEL_EVENTS = {}
+    try:
+        o = ops.attention_fused_kv(qd, kvd, H, D, D ** -0.5, key_mask=km, causal_mask=cm)
+        dq, dkv = torch.autograd.grad((o.float() * cot.to(device).float()).sum(), [qd, kvd])
+        torch.cuda.synchronize()
+        assert set(ops.KERNEL_EVENTS) == {"attn_bf16_fwd_kernel<masked>", "attn_bf16_bwd_kernel<masked>"}, set(ops.KERNEL_EVENTS)
+    finally:
+        ops.KERNEL_EVENTS = None
+    assert o.dtype == torch.bfloat16
+    assert rel_err(o.float(), o_ref2) < 5e-3
+    assert rel_err(dq.float(), gq) < 1e-2
+    assert rel_err(dkv.float(), gkv) < 1e-2
+    if kind == "dead":   # the dead batch: exactly the mean of v over all keys, and no gradient through the scores
+        vmean = kv2.float().view(B, J, 2, H, D)[0, :, 1].mean(0).reshape(1, H * D)
+        assert rel_err(o[0].float().cpu(), vmean.expand(I, -1)) < 5e-3
+        assert float(dq[0].float().abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("variant", ["self", "self_keymask", "cross_ctxmask"])
 def test_module_under_autocast_matches_reference_autocast(device, variant):
+    from amk import ops
     from amk.models import SoftmaxAttention
 
     fx = load_golden("softmax_attention_bf16")
@@ -71,9 +133,18 @@ def test_module_under_autocast_matches_reference_autocast(device, variant):
         kw["context"] = torch.from_numpy(fx["context"]).to(device).requires_grad_(True)
         kw["context_mask"] = torch.from_numpy(fx["ctxmask"]).to(device)
         wrt.append(kw["context"])
-    with torch.autocast("cuda", dtype=torch.bfloat16):
-        out = m(x, **kw)
-    gs = torch.autograd.grad((out.float() * torch.from_numpy(fx["cot"]).to(device)).sum(), wrt + [p for _, p in sorted(m.named_parameters())])
+    ops.KERNEL_EVENTS = {}
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out = m(x, **kw)
+        gs = torch.autograd.grad((out.float() * torch.from_numpy(fx["cot"]).to(device)).sum(), wrt + [p for _, p in sorted(m.named_parameters())])
+        torch.cuda.synchronize()
+        names = {n for n in ops.KERNEL_EVENTS if n.startswith("attn")}
+    finally:
+        ops.KERNEL_EVENTS = None
+    # the core ran on the bf16-MFMA kernels, masked calls included (no upcast to the f32 kernels)
+    sfx = "<masked>" if "context_mask" in kw else ""
+    assert names == {"attn_bf16_fwd_kernel" + sfx, "attn_bf16_bwd_kernel" + sfx}, names
     want, want32 = torch.from_numpy(fx[f"{variant}:out"]), torch.from_numpy(fx[f"{variant}:out_f32"])
     assert rel_err(out.float(), want) < 2e-2
     assert rel_err(out.float(), want32) < 1.5 * ref_err["err_out"]
