@@ -60,6 +60,9 @@ __device__ __forceinline__ f32x16 zero16() {
   return z;
 }
 __device__ __forceinline__ float vmax(float a, float b, float pinf) { return __builtin_amdgcn_fmed3f(a, b, pinf); }
+// v_max3_f32 (this file is built with -fno-honor-nans -mno-amdgpu-ieee, see the Makefile: no canonicalising v_max in front)
+__device__ __forceinline__ float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // transposing read: this lane's 4 elements = one column of a 4-row x 16-column block of 16-bit values
 __device__ __forceinline__ bf16x4 tr_read(const __bf16* p) {
@@ -103,9 +106,11 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
   __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * TSTR];
   __shared__ __attribute__((aligned(16))) float Kfill[MASKED ? 64 : 4];   // MASKED: per key of the tile 0 keep / fill / -inf past J
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = wg % p.nqblk, bh = wg / p.nqblk;
-  const int h = bh % p.H, b = bh / p.H;
+  // (wave-uniform; said explicitly: built without IEEE mode the compiler treats the quotients as divergent and wraps the loads
+  // through the K / V descriptors in waterfall loops)
+  const int wg = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  const int qb = __builtin_amdgcn_readfirstlane(wg % p.nqblk), bh = __builtin_amdgcn_readfirstlane(wg / p.nqblk);
+  const int h = __builtin_amdgcn_readfirstlane(bh % p.H), b = __builtin_amdgcn_readfirstlane(bh / p.H);
   const int qi = qb * 128 + wave * 32 + ln;
   const bool qvalid = qi < p.I;
 
@@ -162,7 +167,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
   };
   const float c2 = p.scale * AMK_LOG2E;
   f32x16 o0 = zero16(), o1 = zero16();
-  float m_run = -INFINITY, l_run = 0.f;   // m_run: running max of the RAW scores
+  float m_run = -INFINITY, l_run = 0.f;   // m_run: running max of the RAW scores (unmasked: a lazy reference, see below)
+  float mc_run = 0.f;                     // m_run * c2
+  const float lazy_tau = 8.f / c2;        // the reference moves when a row's maximum passes it by 2^8 in the exponent
   const int ntile = (p.J + 63) / 64;
   prefetch(0);
   for (int t = 0; t < ntile; ++t) {
@@ -213,31 +220,68 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
         if (ja + 32 >= p.J) s1[r] = -INFINITY;
       }
     }
-    float mx = vmax(s0[0], s1[0], p.pinf);
+    if (!MASKED) {
+      // Unmasked: the lazy reference of csrc/attn_fwd.hip's plain kernel.  softmax does not care which constant is
+      // subtracted, so the reference m_run only has to stay within 2^8 of the true maximum: the 32 accumulator rescales
+      // (paid in almost every tile when 32 independent rows share a wave) become rare, the row maximum is 16 v_max3, the
+      // row sum 16 packed adds.  (m_run, l) leave as the statistics: the backward forms the same P from them.
+      float mx = max3(s0[0], s1[0], s0[1]);
+      mx = max3(mx, s1[1], s0[2]);
 #pragma unroll
-    for (int r = 1; r < 16; ++r) mx = vmax(mx, vmax(s0[r], s1[r], p.pinf), p.pinf);
-    mx = vmax(mx, __shfl_xor(mx, 32, 64), p.pinf);
-    const float m_new = vmax(m_run, mx, p.pinf);
-    const float mc = __fmul_rn(m_new, c2);
-    float lsum = 0.f;
+      for (int r = 2; r < 15; ++r) mx = max3(mx, s1[r], s0[r + 1]);
+      mx = __builtin_fmaxf(mx, s1[15]);
+      mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+      if (t == 0 || __any(mx > m_run + lazy_tau)) {
+        const float m_new = t == 0 ? mx : __builtin_fmaxf(m_run, mx);
+        if (t != 0) {
+          const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c2);
+          l_run *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      // MASKED: two rounded operations, so that s == m gives exactly 0 at any magnitude (a fused multiply-add leaves the
-      // rounding error of m * c2, +-64 at the fill value's 1.4e9)
-      const float p0 = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(s0[r], c2), mc) : __builtin_fmaf(s0[r], c2, -mc));
-      const float p1 = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(s1[r], c2), mc) : __builtin_fmaf(s1[r], c2, -mc));
-      s0[r] = p0;
-      s1[r] = p1;
-      lsum += p0 + p1;
+          for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        }
+        m_run = m_new;
+        mc_run = m_new * c2;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        s0[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], c2, -mc_run));
+        s1[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], c2, -mc_run));
+      }
+      f32x2 la = {0.f, 0.f}, lb = {0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        la += (f32x2){s0[r], s0[r + 1]};
+        lb += (f32x2){s1[r], s1[r + 1]};
+      }
+      la += lb;
+      l_run += la.x + la.y;
+    } else {
+      float mx = vmax(s0[0], s1[0], p.pinf);
+  #pragma unroll
+      for (int r = 1; r < 16; ++r) mx = vmax(mx, vmax(s0[r], s1[r], p.pinf), p.pinf);
+      mx = vmax(mx, __shfl_xor(mx, 32, 64), p.pinf);
+      const float m_new = vmax(m_run, mx, p.pinf);
+      const float mc = __fmul_rn(m_new, c2);
+      float lsum = 0.f;
+  #pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        // MASKED: two rounded operations, so that s == m gives exactly 0 at any magnitude (a fused multiply-add leaves the
+        // rounding error of m * c2, +-64 at the fill value's 1.4e9)
+        const float p0 = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(s0[r], c2), mc) : __builtin_fmaf(s0[r], c2, -mc));
+        const float p1 = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(s1[r], c2), mc) : __builtin_fmaf(s1[r], c2, -mc));
+        s0[r] = p0;
+        s1[r] = p1;
+        lsum += p0 + p1;
+      }
+      if (__any(m_new != m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(m_run, c2), mc) : (m_run - m_new) * c2);
+        l_run *= alpha;
+  #pragma unroll
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        m_run = m_new;
+      }
+      l_run += lsum;
     }
-    if (__any(m_new != m_run)) {
-      const float alpha = __builtin_amdgcn_exp2f(MASKED ? __fsub_rn(__fmul_rn(m_run, c2), mc) : (m_run - m_new) * c2);
-      l_run *= alpha;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      m_run = m_new;
-    }
-    l_run += lsum;
     // ---- O^T += V^T P^T: four 16-key slots x two 32-dim blocks
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -321,9 +365,9 @@ __global__ __launch_bounds__(64 * BW, 1) void attn_bf16_bwd_kernel(Params p) {
   float* stat = reinterpret_cast<float*>(tiles + 2 * STG);          // 2 stages x {-(m + log2 l) / c2, -delta, m, 1 / l} x 32
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int kb = wg % p.nkblk, bh = wg / p.nkblk;
-  const int h = bh % p.H, b = bh / p.H;
+  const int wg = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  const int kb = __builtin_amdgcn_readfirstlane(wg % p.nkblk), bh = __builtin_amdgcn_readfirstlane(wg / p.nkblk);
+  const int h = __builtin_amdgcn_readfirstlane(bh % p.H), b = __builtin_amdgcn_readfirstlane(bh / p.H);
   const int key0 = kb * BKEYS;
   const int key = key0 + 32 * wave + ln;
   const bool kvalid = key < p.J;

@@ -24,6 +24,13 @@
 #include "attn_common.h"
 #include <stdlib.h>
 
+// diagnostic builds only (tools/ablate_attn_bwd.sh): AMK_BWD_ABL bits switch parts of the tile loop off -- WRONG results,
+// timing only: 1 no dq atomics / stores, 2 no dQ product, 4 no dS LDS writes, 8 no P / dS arithmetic, 16 no kept-score
+// loads, 32 no dV / dK column reads (operands reused), 64 no q / dO staging after the first tile
+#ifndef AMK_BWD_ABL
+#define AMK_BWD_ABL 0
+#endif
+
 namespace amk_attn {
 
 constexpr int TQ = 32;             // queries per tile
@@ -258,14 +265,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
         }
       }
     }
-    if (KEPT) {
+    if (KEPT && !(AMK_BWD_ABL & 16)) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         s[4 * g + 0] = sk[g].x; s[4 * g + 1] = sk[g].y; s[4 * g + 2] = sk[g].z; s[4 * g + 3] = sk[g].w;
       }
     }
     // ---- P and dS (register r of this lane is query acc_row(r, hf))
-    if (plain) {
+    if (AMK_BWD_ABL & 8) {
+    } else if (plain) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         // (no fill in this wave's columns, so every row has a live key here and m is a genuine score maximum: the
@@ -304,12 +312,14 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
       }
     }
     // ---- dS -> LDS as [query][key] for the workgroup-wide dQ product
+    if (!(AMK_BWD_ABL & 4)) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) dSl[acc_row(r, hf) * DS_STRIDE + 32 * wave + ln] = dp[r];
+    }
 
     // the next tile's scores (consumed after the next tile's dP product: three MFMA phases from here;
     // the last iteration re-reads its own tile, unused)
-    if (KEPT) {
+    if (KEPT && !(AMK_BWD_ABL & 16)) {
       load_scores(tile_of(min(t + 1, ntile - 1)));
       __builtin_amdgcn_sched_barrier(0);  // issued HERE: the compiler otherwise sinks them below the MFMAs
     }
@@ -318,14 +328,15 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
     // ---- dV^T += dO^T P ; dK^T += (q*scale*log2e)^T dS   (2 x 32 MFMAs)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const float* gc = &Gs[acc_row(r, hf) * LDS_STRIDE + ln];
-      const float* qc = &Qs[acc_row(r, hf) * LDS_STRIDE + ln];
+      const float* gc = &Gs[acc_row((AMK_BWD_ABL & 32) ? 0 : r, hf) * LDS_STRIDE + ln];
+      const float* qc = &Qs[acc_row((AMK_BWD_ABL & 32) ? 0 : r, hf) * LDS_STRIDE + ln];
       dv0 = mfma32(gc[0], s[r], dv0);
       dv1 = mfma32(gc[32], s[r], dv1);
       dk0 = mfma32(qc[0], dp[r], dk0);
       dk1 = mfma32(qc[32], dp[r], dk1);
     }
     __syncthreads();  // every wave's dS columns are in LDS; the q / dO / stats tiles are dead
+    if (!(AMK_BWD_ABL & 64)) {
     commit();         // (the last iteration commits a tile nobody reads)
     {
       const int nx = tile_of(min(t + 2, ntile - 1));
@@ -333,12 +344,13 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
       gload.seek(nx, p.dos.st, tid);
       prefetch(nx * TQ);
     }
+    }
 
     // ---- dQ (16 queries x 16*NBLK columns per wave) = dS (16 x KB) K (KB x 16*NBLK): 64 MFMAs 16x16x4,
     //      two independent accumulator chains either way (two blocks, or even / odd k-steps of one)
     f32x4 q0 = {0.f, 0.f, 0.f, 0.f}, q1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int s4 = 0; s4 < KPG / 4; ++s4) {
+    for (int s4 = 0; s4 < ((AMK_BWD_ABL & 2) ? 0 : KPG / 4); ++s4) {
       const float4 a = ld4(ds_row + 4 * s4);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -359,7 +371,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attn_bwd_fused_kernel(BwdParams p)
       const int off = (int)(((int64_t)qi0 * p.dqs.st + dcol0 + c16) * 4);
       const int rstep = (int)(p.dqs.st * 4);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
+      for (int r = 0; r < ((AMK_BWD_ABL & 1) ? 0 : 4); ++r) {
         if (DQ == 0) {
           if (G::NBLK == 2) {
             __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(q0[r] * sc, dq_rsrc, off + r * rstep, 0, 0);
