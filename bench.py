@@ -432,9 +432,10 @@ def secondary_main(args, world, rank, dev, n_ranks_seen):
     note(f"warm-up done ({graph}; {graph_why})")
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         loss = step.step(*data)
-    t_host = time.perf_counter() - t0
+        if i == min(args.steps, 3) - 1:
+            t_host = (time.perf_counter() - t0) / (i + 1) * args.steps   # (first three: later ones can block on a full device queue)
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -593,9 +594,12 @@ def main():
     def timed_steps(n):
         sync()
         t0 = time.perf_counter()
-        for _ in range(n):
+        for i in range(n):
             logs = trainer.step(imgs)
-        host_enqueue[0] = (time.perf_counter() - t0) / n   # host time to ENQUEUE a step (before the synchronise)
+            if i == min(n, 3) - 1:
+                # host time to ENQUEUE a step, over the first three (later ones can block on a full device queue: that
+                # is the device's pace, not the host's)
+                host_enqueue[0] = (time.perf_counter() - t0) / (i + 1)
         sync()
         return time.perf_counter() - t0, logs
 

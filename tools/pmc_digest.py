@@ -32,6 +32,8 @@ def short(name):
         return base + ("(kept scores)" if len(t) > 1 and t[1] == "true" else "")
     if base == "attn_fwd_kernel" and targs.endswith(",true>"):
         return "attn_fwd_keep_kernel"
+    if base == "attn_fwd_plain_kernel":   # the unmasked forward (round 4): <KEEP>
+        return "attn_fwd_keep_kernel" if targs == "<true>" else "attn_fwd_kernel"
     return base
 
 

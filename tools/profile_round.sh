@@ -1,8 +1,8 @@
 # rocprofv3 evidence of a round (run on the GPU box through gpurun; ROUND=r02 by default):
 #   kernel-trace stats of the bench command + four separate --pmc passes over the kernel micro-benchmarks
 set -e
-R=$GRAFT_REPO_ROOT
-ROUND=${ROUND:-r02}
+R=${GRAFT_REPO_ROOT:-/root/repo}
+ROUND=${ROUND:-r04}
 cd /tmp && export TMPDIR=/tmp
 O=$R/gpurun_out/${ROUND}prof
 mkdir -p $O
