@@ -72,7 +72,7 @@ class GradReducer:
         # 83 ms of host time per replay of the 2500-launch GAN step against 0.13 ms for the single-stream graph), and a
         # 90 MB all-reduce left un-overlapped costs less than that.
         self.overlap = bool(overlap) and os.environ.get("AMK_DP_OVERLAP", "1") == "1"
-        self.side = torch.cuda.Stream(device=dev) if self.on_gpu and self.overlap else None
+        self.side = torch.cuda.Stream(device=dev) if self.on_gpu else None   # (`overlap` may be switched between steps)
         self.sync_step = True
         self.active = False
         self._warned_idle = False

@@ -1,5 +1,7 @@
-"""nn.Linear / nn.LayerNorm with the same parameters and state_dict keys, routed through the
-epilogue kernels of libamk.so (amk_add_layernorm_*, amk_colsum) when the input is on the GPU."""
+"""nn.Linear / nn.LayerNorm with the same parameters and state_dict keys, routed through libamk.so when the input is on
+the GPU: Linear through ops.linear -- the own exact-f32 MFMA GEMMs of csrc/gemm_f32.hip (amk_gemm_f32: forward, weight +
+bias gradient in one pass) or the vendor GEMM, as ops.DENSE_MODE decides per shape; bf16 kernels under autocast --,
+LayerNorm through amk_add_layernorm_* (residual add and normalisation in one kernel)."""
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -10,7 +12,7 @@ class Linear(nn.Linear):
     def forward(self, x):
         if not x.is_cuda:
             return F.linear(x, self.weight, self.bias)
-        return ops.linear(x, self.weight, self.bias)   # library GEMM + amk_colsum, or the split-bf16 GEMM (ops.GEMM_MODE)
+        return ops.linear(x, self.weight, self.bias)   # (ops.DENSE_MODE / ops.GEMM_MODE pick the GEMM)
 
 
 class LayerNorm(nn.LayerNorm):

@@ -217,6 +217,17 @@ class SupervisedTrainStep:
                     "state_dict": {k: v.detach().cpu() for k, v in self.model.state_dict().items()}}, path)
 
 
+    def resume_from_checkpoint(self, path):
+        """trainers/utils/base_trainer.py:110-115: step + model weights (no optimizer / scheduler state, as the reference)."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=True)
+        self.global_step = int(ckpt["step"])
+        self.model.load_state_dict(ckpt["state_dict"])
+        self.red.broadcast_parameters()
+        if self.fused_optimizer:
+            self.optim.refresh_shadow()
+        return ckpt.get("config")
+
+
 class ClassifierTrainStep(SupervisedTrainStep):
     """trainers/vit.py: AdamW(lr, betas) -- torch's default weight decay 0.01 (:29) --, CrossEntropyLoss (:31) on the
     logits computed under autocast (:67-71: the loss itself sits outside the autocast block), cosine schedule with warm-up

@@ -314,7 +314,7 @@ def vitmoe_block(dev, batch=64, steps=10):
 
 
 def dp_graph_ok(dev, world):
-    """Can this process group's collectives be captured into a HIP graph?  A pre-flight on a 1-MiB buffer: an all-reduce
+    """Can this process group's collectives be captured into a HIP graph?  A pre-flight on a bucket-sized buffer: an all-reduce
     on a side stream inside a capture, two replays, the result checked; every rank must agree (MIN over ranks), else the
     data-parallel step runs eagerly.  World of one: nothing to capture."""
     if world == 1 and not dist.is_initialized():
@@ -325,7 +325,7 @@ def dp_graph_ok(dev, world):
         return False, f"backend {dist.get_backend()} cannot be captured"
     ok, why = 1.0, "probe passed"
     try:
-        buf = torch.ones(1 << 18, device=dev)
+        buf = torch.ones(8 << 20, device=dev)   # 32 MiB: one gradient bucket (the protocol RCCL picks depends on the size)
         side = torch.cuda.Stream(device=dev)
         dist.all_reduce(buf, op=dist.ReduceOp.AVG)   # communicator warm-up outside the capture
         torch.cuda.synchronize()
@@ -355,6 +355,30 @@ def dp_graph_ok(dev, world):
     if float(t.item()) < 1.0 and ok == 1.0:
         why = "probe failed on another rank"
     return float(t.item()) >= 1.0, why
+
+
+def capture_or_eager(capture, release, reducers, world, dev):
+    """Capture the step; with several ranks every rank must have succeeded (MIN over ranks, an eager collective: the ones
+    inside a capture were recorded, not run) -- otherwise every rank drops its graph and the step runs eagerly, with the
+    all-reduces back on the side stream.  Returns (graphed, reason)."""
+    ok, why = 1.0, "captured"
+    try:
+        capture()
+    except Exception as e:  # noqa: BLE001
+        ok, why = 0.0, f"capture raised {type(e).__name__}: {e}"
+        note(why)
+    if dist.is_initialized():
+        t = torch.tensor([ok], device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        if float(t.item()) < 1.0 and ok == 1.0:
+            why = "capture failed on another rank"
+        ok = float(t.item())
+    if ok < 1.0:
+        release()
+        for red in reducers:
+            red.overlap = True
+        return False, why
+    return True, why
 
 
 SECONDARY = {
@@ -427,8 +451,11 @@ def secondary_main(args, world, rank, dev, n_ranks_seen):
         step.step(*data)
     graph = "eager"
     if can_graph:
-        step.capture(*data)
-        graph = "one HIP-graph replay per step" + (" (RCCL all-reduces captured inside)" if not step.red.alone else "")
+        done, cap_why = capture_or_eager(lambda: step.capture(*data), step.release_graph, [step.red], world, dev)
+        if done:
+            graph = "one HIP-graph replay per step" + (" (RCCL all-reduces captured inside)" if not step.red.alone else "")
+        else:
+            graph_why = cap_why
     note(f"warm-up done ({graph}; {graph_why})")
     sync()
     t0 = time.perf_counter()
@@ -607,7 +634,9 @@ def main():
     for _ in range(args.warmup):
         trainer.step(imgs)
     if use_graph:
-        trainer.capture(imgs)
+        use_graph, cap_why = capture_or_eager(lambda: trainer.capture(imgs), trainer.release_graph, [trainer.g_red, trainer.d_red], world, dev)
+        if not use_graph:
+            graph_why, overlap = cap_why, True
     note("warm-up done" + (" (step captured into a HIP graph)" if use_graph else ""))
     # ---- the headline: EXACTLY --steps steps, no instrumentation, barrier + synchronize on both sides
     dt, logs = timed_steps(args.steps)
