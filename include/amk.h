@@ -54,9 +54,12 @@ const char* amk_last_error(void);
  *   S = -1e9 where key_mask[b,j] == 0          (reference: masked_fill(~context_mask))
  *   S = -1e9 where causal_mask[i,j] != 0       (reference: masked_fill(causal_mask))
  *   P = softmax_j(S);  o[b,h,i,:] = sum_j P[b,h,i,j] v[b,h,j,:]
- *   stats[b,h,i] = { m, l }: m = max_j S*log2(e), l = sum_j exp2(S*log2(e) - m)
- *                 (saved for the backward; two floats per row so that a fully
- *                  masked row, S = -1e9 everywhere, keeps its exact 1/J weights)
+ *   stats[b,h,i] = { m, l }: a row reference m in the log2 domain and l = sum_j exp2(S*log2(e) - m)
+ *                 (saved for the backward, which forms P = exp2(S*log2(e) - m) / l; two floats per row so
+ *                  that a fully masked row, S = -1e9 everywhere, keeps its exact 1/J weights).
+ *                 With a mask m = max_j S*log2(e); without masks (D = 64) m is a reference within 8 of
+ *                 that maximum -- it moves only when a tile's maximum passes it by more than 8 -- and l
+ *                 is the sum relative to it: the same P.
  *
  * q/o are addressed as  base + b*sb + t*st + h*sh + d   (d < D contiguous), so
  * the (B,T,h*D) projection outputs are consumed in place (st = h*D, sh = D) as
