@@ -117,6 +117,7 @@ class SupervisedTrainStep:
         self._micro = 0          # accelerator.step: calls of accumulate() so far
         self._lr_arg = 0         # the index the scheduler was last stepped with
         self._graph = None
+        self._accum_graph = None
         self.last_lr = None
 
     # ---- what a subclass provides
@@ -206,6 +207,57 @@ class SupervisedTrainStep:
 
     def release_graph(self):
         self._graph = None
+        self._accum_graph = None
+
+    # ---- one optimizer step over accum_steps micro-batches (the shipped Muse / MaskGit schedules: batch 1-8 x 16-32
+    # accumulation steps, cfg/muse.yaml:51,80, cfg/maskgit.yaml:45,75 -- host-bound launch by launch)
+    def _accum_body(self, k):
+        n = self.accum_steps
+
+        def body(*xs):
+            for i in range(n - 1):
+                self.step_body(False, *xs[i * k:(i + 1) * k])
+            return self.step_body(True, *xs[(n - 1) * k:])
+        return body
+
+    def _tick_accum(self):
+        n = self.accum_steps
+        self._micro += n
+        self._set_lr()
+        self._lr_arg = self.global_step + n - 1
+        self.global_step += n
+
+    def capture_accumulated(self, micro_batches, warmup=2):
+        """Capture a whole optimizer step -- accum_steps micro-batches (each a tuple of tensors), the last one synchronising
+        -- into ONE HIP graph; step_accumulated() then replays it.  Same conditions as capture()."""
+        from .graphs import GraphedStep
+
+        if len(micro_batches) != self.accum_steps:
+            raise ValueError(f"capture_accumulated: {len(micro_batches)} micro-batches for accum_steps={self.accum_steps}")
+        if not self.red.alone and not self.red.avg_in_collective:
+            raise RuntimeError("capture_accumulated(): only RCCL (backend 'nccl') collectives can be captured into a HIP graph")
+        k = len(micro_batches[0])
+        self._accum_graph = None
+        self._accum_graph = GraphedStep(self._accum_body(k), [t for mb in micro_batches for t in mb], warmup=warmup,
+                                        before_each=self._tick_accum)
+
+    def step_accumulated(self, micro_batches):
+        """accum_steps iterations of the reference loop at once (call it on optimizer-step boundaries): a replay of
+        capture_accumulated()'s graph when the shapes match, else eager micro-steps.  Returns the last micro-batch's loss."""
+        n = self.accum_steps
+        if len(micro_batches) != n or self._micro % n != 0:
+            raise ValueError("step_accumulated: pass accum_steps micro-batches, starting on an optimizer-step boundary")
+        flat = [t for mb in micro_batches for t in mb]
+        self._micro += n
+        self._set_lr()
+        g = getattr(self, "_accum_graph", None)
+        if g is not None and len(flat) == len(g.static_inputs) and all(a.shape == b.shape for a, b in zip(flat, g.static_inputs)):
+            loss = g.replay(*flat)
+        else:
+            loss = self._accum_body(len(micro_batches[0]))(*flat)
+        self._lr_arg = self.global_step + n - 1      # the synchronising iteration's scheduler.step(self.global_step)
+        self.global_step += n
+        return loss
 
     def save_ckpt(self, path, config=None):
         """trainers/utils/base_trainer.py:92-107: {'step', 'state_dict', 'config'}, main process only."""

@@ -309,3 +309,41 @@ def test_masked_token_step_frozen_vq(device):
     assert torch.isfinite(loss)
     for n, p in vq.named_parameters():
         assert torch.equal(p, vq0[n]), n
+
+
+def test_accumulated_step_captured_as_one_graph(device):
+    """The shipped Muse schedule in miniature (cfg/muse.yaml:51,80: tiny batches, many accumulation steps): accum_steps
+    micro-batches and the optimizer step as ONE graph replay equal the same iterations run one by one -- parameters and
+    schedule position -- with FlatAdam as plain Adam-with-L2 (cfg/maskgit.yaml:59) and no clipping (max_grad_norm null)."""
+    from amk import ops
+    from amk.models import ViTMoE
+    from amk.train import ClassifierTrainStep
+
+    old = ops.DETERMINISTIC_ATTENTION_BACKWARD
+    ops.DETERMINISTIC_ATTENTION_BACKWARD = True
+    try:
+        torch.manual_seed(0)
+        base = ViTMoE(**SMALL_MOE).to(device)
+        g = torch.Generator().manual_seed(8)
+        mbs = [(torch.randn(2, 3, 64, 64, generator=g).to(device), torch.randint(0, 10, (2,), generator=g).to(device)) for _ in range(4)]
+        runs = []
+        for graphed in (False, True):
+            model = copy.deepcopy(base)
+            ts = ClassifierTrainStep(model, lr=1e-3, weight_decay=0.01, decoupled=False, warmup_steps=2, total_steps=40,
+                                     max_grad_norm=None, accum_steps=4, bucket_bytes=256 << 10, capturable=True)
+            if graphed:
+                ts.capture_accumulated(mbs, warmup=1)
+                for _ in range(2):
+                    ts.step_accumulated(mbs)
+            else:
+                for _ in range(3):
+                    for mb in mbs:
+                        ts.step(*mb)
+            torch.cuda.synchronize()
+            runs.append(([p.detach().clone() for p in model.parameters()], ts.global_step, ts.last_lr))
+        (p0, s0, lr0), (p1, s1, lr1) = runs
+        assert s0 == s1 == 12 and lr0 == lr1
+        for a, b in zip(p0, p1):
+            assert torch.equal(a, b)
+    finally:
+        ops.DETERMINISTIC_ATTENTION_BACKWARD = old
