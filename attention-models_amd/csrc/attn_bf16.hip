@@ -102,9 +102,11 @@ __device__ __forceinline__ void lds_barrier_bf() {
 // ---------------------------------------------------------------------------------------------------------------
 template <bool MASKED>
 __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
-  __shared__ __attribute__((aligned(16))) __bf16 Ks[64 * KSTR];
-  __shared__ __attribute__((aligned(16))) __bf16 Vs[64 * TSTR];
-  __shared__ __attribute__((aligned(16))) float Kfill[MASKED ? 64 : 4];   // MASKED: per key of the tile 0 keep / fill / -inf past J
+  // two LDS stages: tile t + 1 is committed while tile t is being read, ONE barrier per tile (round 4; the single-stage
+  // loop had two, and at ~1700 cycles per tile the pair showed)
+  __shared__ __attribute__((aligned(16))) __bf16 Ks2[2][64 * KSTR];
+  __shared__ __attribute__((aligned(16))) __bf16 Vs2[2][64 * TSTR];
+  __shared__ __attribute__((aligned(16))) float Kfill2[2][MASKED ? 64 : 4];   // MASKED: per key of the tile 0 keep / fill / -inf past J
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), ln = lane & 31, hf = lane >> 5;
   // (wave-uniform; said explicitly: built without IEEE mode the compiler treats the quotients as divergent and wraps the loads
   // through the K / V descriptors in waterfall loops)
@@ -157,13 +159,13 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
       fillst = j >= p.J ? -INFINITY : (keep ? 0.f : fill_raw);
     }
   };
-  auto commit = [&]() {
+  auto commit = [&](int stage) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<float4*>(&Ks[(srow + 32 * i) * KSTR + sch]) = kst[i];
-      *reinterpret_cast<float4*>(&Vs[(srow + 32 * i) * TSTR + sch]) = vst[i];
+      *reinterpret_cast<float4*>(&Ks2[stage][(srow + 32 * i) * KSTR + sch]) = kst[i];
+      *reinterpret_cast<float4*>(&Vs2[stage][(srow + 32 * i) * TSTR + sch]) = vst[i];
     }
-    if (MASKED) Kfill[tid & 63] = fillst;   // (four waves write the same 64 values)
+    if (MASKED) Kfill2[stage][tid & 63] = fillst;   // (four waves write the same 64 values)
   };
   const float c2 = p.scale * AMK_LOG2E;
   f32x16 o0 = zero16(), o1 = zero16();
@@ -172,13 +174,15 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
   const float lazy_tau = 8.f / c2;        // the reference moves when a row's maximum passes it by 2^8 in the exponent
   const int ntile = (p.J + 63) / 64;
   prefetch(0);
+  commit(0);
+  prefetch(1);         // (unconditional throughout: a tile past the sequence is outside the descriptors and reads zeros; a
+                       //  branch around a memory instruction would make every wait of the loop a full drain)
+  lds_barrier_bf();
   for (int t = 0; t < ntile; ++t) {
     const int j0 = t * 64;
-    lds_barrier_bf();
-    commit();
-    lds_barrier_bf();
-    prefetch(t + 1);   // (unconditional: a tile past the sequence is outside the descriptors and reads zeros; a branch around
-                       //  a memory instruction would make every wait of the loop a full drain)
+    const __bf16* Ks = Ks2[t & 1];
+    const __bf16* Vs = Vs2[t & 1];
+    const float* Kfill = Kfill2[t & 1];
     // ---- S^T = K Q^T: two 32-key blocks x four 16-deep steps
     f32x16 s0 = zero16(), s1 = zero16();
 #pragma unroll
@@ -292,6 +296,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_fwd_kernel(Params p) {
       o0 = mfmab(va, pp, o0);
       o1 = mfmab(vb, pp, o1);
     }
+    commit((t + 1) & 1);   // tile t + 1 (requested a tile ago) into the other stage; past the last tile: zeros nobody reads
+    prefetch(t + 2);
+    lds_barrier_bf();      // every wave is done with stage t & 1 and has written its part of stage (t + 1) & 1
   }
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
   const float inv = 1.f / l_tot;
