@@ -142,3 +142,40 @@ def test_bf16_resume_and_shared_forward(device, tmp_path):
         logs = c.step(imgs)
     assert all(bool(torch.isfinite(v)) for v in logs.values())
     assert all(bool(torch.isfinite(p).all()) for p in c.model.parameters())
+
+
+def test_muse_decoder_with_padded_prompt_under_bf16_autocast(device):
+    """models/muse.py:88-96 with a key-padding mask on the text positions (a padded prompt), under the reference's autocast
+    setting: the cross-attention (1024-token-like queries x padded text keys) runs on the MASKED bf16-MFMA kernels -- not on
+    the f32 kernels with upcast inputs, as until round 3 -- and stays within bf16 rounding of the f32 pass."""
+    from amk import ops
+    from amk.models.muse import BidirectionalDecoder
+
+    torch.manual_seed(0)
+    dec = BidirectionalDecoder(dim=128, codebook_size=64, n_heads=2, d_head=64, depth=2, mult=2, dropout=0.0, num_patches=96).to(device)
+    ids = torch.randint(0, 65, (3, 96), device=device)
+    ctx = torch.randn(3, 20, 128, device=device)
+    keep = torch.ones(3, 20, dtype=torch.bool, device=device)
+    keep[0, 7:] = False
+    keep[1, 13:] = False
+    cot = torch.randn(3, 96, 64, device=device)
+    out32 = dec(ids, context=ctx, context_mask=keep)
+    g32 = torch.autograd.grad((out32 * cot).sum(), [p for p in dec.parameters() if p.requires_grad], allow_unused=True)
+    ops.KERNEL_EVENTS = {}
+    try:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            out16 = dec(ids, context=ctx, context_mask=keep)
+        g16 = torch.autograd.grad((out16.float() * cot).sum(), [p for p in dec.parameters() if p.requires_grad], allow_unused=True)
+        torch.cuda.synchronize()
+        names = set(ops.KERNEL_EVENTS)
+    finally:
+        ops.KERNEL_EVENTS = None
+    assert "attn_bf16_fwd_kernel<masked>" in names and "attn_bf16_bwd_kernel<masked>" in names, names   # the cross-attention
+    assert "attn_bf16_fwd_kernel" in names                                                            # the (unmasked) self-attention
+    assert not any(n.startswith("attn_fwd") or n.startswith("attn_bwd") for n in names), names        # no f32 attention kernel ran
+    err = float((out16.detach().float() - out32.detach()).abs().max() / out32.detach().abs().max())
+    assert err < 3e-2, err
+    for a, b in zip(g16, g32):
+        if b is not None:
+            assert a is not None and torch.isfinite(a).all()
+            assert float((a.float() - b).abs().max()) <= 6e-2 * float(b.abs().max()) + 1e-6
