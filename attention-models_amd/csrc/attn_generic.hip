@@ -6,6 +6,7 @@
 // ones (software-pipelined operand reads, kept scores, the one-pass backward) -- these are the
 // plain form: forward, and the two reproducible recompute kernels for the backward.
 #include "attn_common.h"
+#include <type_traits>
 
 namespace amk_attn {
 
@@ -61,10 +62,10 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_kernel(Fw
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 31, hf = lane >> 5;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = wg % p.nblk;
-  const int bh = wg / p.nblk;
-  const int h = bh % p.H, b = bh / p.H;
+  const int wg = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  const int qb = __builtin_amdgcn_readfirstlane(wg % p.nblk);
+  const int bh = __builtin_amdgcn_readfirstlane(wg / p.nblk);
+  const int h = __builtin_amdgcn_readfirstlane(bh % p.H), b = __builtin_amdgcn_readfirstlane(bh / p.H);
   const int qi = qb * BLK + wave * 32 + ln;
   const bool qvalid = qi < p.I;
 
@@ -202,6 +203,181 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_kernel(Fw
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// The forward WITHOUT masks for head dims 32 / 128 (round 4): attn_fwd_plain_kernel of attn_fwd.hip with the head dim as a
+// template parameter -- lazy softmax reference held in the MFMA accumulators (-m_ref is the C operand that opens every
+// S^T chain; the reference moves only when a row's tile maximum passes it by 2^8), v_max3 row maxima, packed row sums,
+// no fill path (the ragged last tile is a peeled copy of the tile body), operand fragments read a step ahead.  (m_ref, l)
+// leave as the statistics; the recompute backward forms exp2(S - m_ref) / l, the same P.
+__device__ __forceinline__ float gmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+template <int DH>
+__global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_plain_kernel(FwdParams p) {
+  using G = GenGeom<DH>;
+  constexpr int HD = G::HD, LS = G::LS, NT = G::NT, TL = G::TL, NS = G::NS;
+  constexpr float TAU = 8.f;
+  __shared__ __attribute__((aligned(16))) float smem[2 * TL * LS];
+  float* Ks = smem;
+  float* Vs = smem + TL * LS;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 31, hf = lane >> 5;
+  // (wave-uniform; said explicitly because this file is built without IEEE mode: see attn_fwd_plain_kernel)
+  const int wg = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  const int qb = __builtin_amdgcn_readfirstlane(wg % p.nblk);
+  const int bh = __builtin_amdgcn_readfirstlane(wg / p.nblk);
+  const int h = __builtin_amdgcn_readfirstlane(bh % p.H), b = __builtin_amdgcn_readfirstlane(bh / p.H);
+  const int qi = qb * BLK + wave * 32 + ln;
+  const bool qvalid = qi < p.I;
+
+  const float qscale = p.scale * AMK_LOG2E;
+  float qreg[HD];
+  {
+    const float* qp = p.q + (int64_t)b * p.qs.sb + (int64_t)qi * p.qs.st + (int64_t)h * p.qs.sh + HD * hf;
+#pragma unroll
+    for (int s4 = 0; s4 < HD / 4; ++s4) {
+      const float4 t = qvalid ? ld4(qp + 4 * s4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      qreg[4 * s4 + 0] = t.x * qscale; qreg[4 * s4 + 1] = t.y * qscale;
+      qreg[4 * s4 + 2] = t.z * qscale; qreg[4 * s4 + 3] = t.w * qscale;
+    }
+  }
+  const float* kbase = p.k + (int64_t)b * p.ks.sb + (int64_t)h * p.ks.sh;
+  const float* vbase = p.v + (int64_t)b * p.vs.sb + (int64_t)h * p.vs.sh;
+  float4 kst[G::NP], vst[G::NP];
+  GenStager<DH> kload, vload;
+  kload.init(kbase, p.ks.st, p.J, tid);
+  vload.init(vbase, p.vs.st, p.J, tid);
+  auto prefetch = [&]() {
+    kload.load(kst);
+    vload.load(vst);
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int ps = 0; ps < G::NP; ++ps) {
+      st4(&Ks[GenStager<DH>::lds_off(tid, ps)], kst[ps]);
+      st4(&Vs[GenStager<DH>::lds_off(tid, ps)], vst[ps]);
+    }
+  };
+
+  f32x16 o[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n) o[n] = zero16();
+  f32x16 negm = zero16();
+  float mref = 0.f, l_run = 0.f;
+  const int ntile = (p.J + TL - 1) / TL;
+  const int nfull = p.J / TL;
+
+  auto tile = [&](const int t, auto ragged_c) {
+    constexpr bool RAGGED = decltype(ragged_c)::value;
+    __syncthreads();
+    commit();
+    __syncthreads();
+    if (t + 1 < ntile) prefetch();
+
+    f32x16 s[NS];
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      s[u] = negm;
+      const float* kr = &Ks[(32 * u + ln) * LS + HD * hf];
+      float4 a = ld4(kr);
+#pragma unroll
+      for (int s4 = 0; s4 < HD / 4; ++s4) {
+        float4 nx = a;
+        if (s4 + 1 < HD / 4) nx = ld4(kr + 4 * (s4 + 1));   // the next k-block's fragment, one step ahead of its MFMAs
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[u] = mfma32(f4(a, e), qreg[4 * s4 + e], s[u]);
+        a = nx;
+      }
+    }
+    if (RAGGED) {
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][r] = (t * TL + 32 * u + acc_row(r, hf) < p.J) ? s[u][r] : -INFINITY;
+    }
+    float mx = gmax3(s[0][0], s[0][1], s[0][2]);
+#pragma unroll
+    for (int r = 3; r + 1 < 16; r += 2) mx = gmax3(mx, s[0][r], s[0][r + 1]);
+    mx = __builtin_fmaxf(mx, s[0][15]);
+#pragma unroll
+    for (int u = 1; u < NS; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) mx = gmax3(mx, s[u][r], s[u][r + 1]);
+    mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (t == 0 || __any(mx > TAU)) {   // rare after the first tile
+      const float d = t == 0 ? mx : __builtin_fmaxf(mx, 0.f);
+      if (t != 0) {
+        const float alpha = __builtin_amdgcn_exp2f(-d);
+        l_run *= alpha;
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
+      }
+      mref += d;
+#pragma unroll
+      for (int u = 0; u < NS; ++u)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s[u][r] -= d;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) negm[r] = -mref;
+    }
+    f32x2 ls = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[u][r] = __builtin_amdgcn_exp2f(s[u][r]);
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) ls += (f32x2){s[u][r], s[u][r + 1]};
+    }
+    l_run += ls.x + ls.y;
+    // O^T += V^T P^T, the V column fragments of step r + 1 read under the MFMAs of step r
+#pragma unroll
+    for (int u = 0; u < NS; ++u) {
+      float c[NT], nx[NT];
+      {
+        const float* vc = &Vs[(32 * u + acc_row(0, hf)) * LS + ln];
+#pragma unroll
+        for (int n = 0; n < NT; ++n) c[n] = vc[32 * n];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        if (r + 1 < 16) {
+          const float* vc = &Vs[(32 * u + acc_row(r + 1, hf)) * LS + ln];
+#pragma unroll
+          for (int n = 0; n < NT; ++n) nx[n] = vc[32 * n];
+        }
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[n] = mfma32(c[n], s[u][r], o[n]);
+#pragma unroll
+        for (int n = 0; n < NT; ++n) c[n] = nx[n];
+      }
+    }
+  };
+
+  prefetch();
+  for (int t = 0; t < nfull; ++t) tile(t, std::false_type{});
+  if (nfull < ntile) tile(nfull, std::true_type{});
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (qvalid) {
+    float* op = p.o + (int64_t)b * p.os.sb + (int64_t)qi * p.os.st + (int64_t)h * p.os.sh + 4 * hf;
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        st4(op + 32 * n + 8 * g, make_float4(o[n][4 * g] * inv, o[n][4 * g + 1] * inv, o[n][4 * g + 2] * inv, o[n][4 * g + 3] * inv));
+    if (hf == 0) {
+      float* sp = p.stats + (((int64_t)b * p.H + h) * p.I + qi) * 2;
+      sp[0] = mref;
+      sp[1] = l_tot;
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 template <int DH>
 __global__ __launch_bounds__(256) void attn_bwd_delta_gen_kernel(BwdParams p) {
@@ -238,10 +414,10 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_bwd_dq_gen_kernel
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 31, hf = lane >> 5;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int qb = wg % p.nqblk;
-  const int bh = wg / p.nqblk;
-  const int h = bh % p.H, b = bh / p.H;
+  const int wg = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  const int qb = __builtin_amdgcn_readfirstlane(wg % p.nqblk);
+  const int bh = __builtin_amdgcn_readfirstlane(wg / p.nqblk);
+  const int h = __builtin_amdgcn_readfirstlane(bh % p.H), b = __builtin_amdgcn_readfirstlane(bh / p.H);
   const int qi = qb * BLK + wave * 32 + ln;
   const bool qvalid = qi < p.I;
 
@@ -374,10 +550,10 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_bwd_dkdv_gen_kern
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int ln = lane & 31, hf = lane >> 5;
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  const int kb = wg % p.nkblk;
-  const int bh = wg / p.nkblk;
-  const int h = bh % p.H, b = bh / p.H;
+  const int wg = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x));
+  const int kb = __builtin_amdgcn_readfirstlane(wg % p.nkblk);
+  const int bh = __builtin_amdgcn_readfirstlane(wg / p.nkblk);
+  const int h = __builtin_amdgcn_readfirstlane(bh % p.H), b = __builtin_amdgcn_readfirstlane(bh / p.H);
   const int kj = kb * BLK + wave * 32 + ln;
   const bool kvalid = kj < p.J;
 
@@ -507,6 +683,7 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_bwd_dkdv_gen_kern
 template <int DH>
 static void launch_fwd_gen(const FwdParams& p, int64_t nwg, hipStream_t st) {
   if (p.causal_mask) hipLaunchKernelGGL((attn_fwd_gen_kernel<DH, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
+  else if (!p.key_mask) hipLaunchKernelGGL((attn_fwd_gen_plain_kernel<DH>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   else hipLaunchKernelGGL((attn_fwd_gen_kernel<DH, false>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
 }
 
