@@ -488,6 +488,70 @@ def secondary_main(args, world, rank, dev, n_ranks_seen):
         dist.destroy_process_group()
 
 
+def rccl_world_of_one_block(args, dev, init_state, imgs):
+    """Informational, one-GPU runs only: the data-parallel form of the headline step on THIS box -- a world of one rank that
+    issues its RCCL all-reduces anyway (GradReducer(communicate_when_alone=True)), captured into one HIP graph with the
+    collectives inside (compute-stream all-reduces, as `--dp-overlap auto` picks for this model) and, for comparison, eager
+    with the all-reduces on the side stream.  What N > 1 ranks execute, minus the wire."""
+    import socket
+
+    from amk.models import ViTVQGAN
+    from amk.models.discriminator import NLayerDiscriminator
+    from amk.train import VQGANTrainStep
+
+    out = {"what": "the headline step as its data-parallel form on one GPU: RCCL world of one rank, all-reduces issued "
+                   "(AMK_BENCH_RCCL_ALONE=1 runs the whole bench this way); not the headline value"}
+    try:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"init_process_group: {type(e).__name__}: {e}"
+        return out
+    try:
+        ok, why = dp_graph_ok(dev, 1)
+        out["capture_preflight"] = why
+        for mode in (("graph", False), ("eager", True)):
+            if mode[0] == "graph" and not ok:
+                continue
+            torch.manual_seed(0)
+            model = ViTVQGAN(VIT, CODEBOOK)
+            model.load_state_dict(init_state)
+            model = model.to(dev)
+            discr = NLayerDiscriminator(3, 64, 3).to(dev)
+            tr = VQGANTrainStep(model, discr, capturable=mode[0] == "graph", communicate_when_alone=True, overlap=mode[1])
+            for _ in range(2):
+                tr.step(imgs)
+            if mode[0] == "graph":
+                done, why2 = capture_or_eager(lambda: tr.capture(imgs), tr.release_graph, [tr.g_red, tr.d_red], 1, dev)
+                if not done:
+                    out["graph"] = {"error": why2}
+                    continue
+            n = max(3, min(args.steps, 10))
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(n):
+                tr.step(imgs)
+                if i == 2:
+                    t_host = (time.perf_counter() - t0) / 3
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / n
+            out[mode[0]] = {"ms_per_step": dt * 1e3, "host_enqueue_ms": t_host * 1e3, "images_per_s": args.batch / dt,
+                            "dp_allreduce": "side stream, overlapped with backward" if mode[1] else "compute stream, at bucket completion",
+                            "buckets": len(tr.g_red.buckets) + len(tr.d_red.buckets),
+                            "gradient_bytes": tr.g_red.grads_nbytes() + tr.d_red.grads_nbytes()}
+            tr.release_graph()
+            del tr, model, discr
+            torch.cuda.empty_cache()
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    finally:
+        dist.destroy_process_group()
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: start the N rank processes from here.  The parent
     never touches HIP (no torch.cuda call), passes its own flags through, relays rank 0's JSON line and
@@ -767,6 +831,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_kernels and not args.no_variants:
         agent = agent_block(dev, args.kernel_iters)
         note("AgentAttention block done")
+    dp_one = None
+    if rank == 0 and world == 1 and not alone_rccl and not args.no_variants and not bf16:
+        trainer.release_graph()
+        dp_one = rccl_world_of_one_block(args, dev, init_state, imgs)
+        note("RCCL world-of-one block done")
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import train_step_cpu
@@ -881,6 +950,11 @@ def main():
             line["kernels_vitmoe"] = vitmoe
         if agent:
             line["kernels_agent"] = agent
+        if dp_one:
+            line["dp_step_rccl_world_of_one"] = dp_one
+            if "graph" in dp_one and "ms_per_step" in dp_one.get("graph", {}):
+                line["dp_captured_ms_per_step"] = dp_one["graph"]["ms_per_step"]
+                line["dp_captured_host_enqueue_ms"] = dp_one["graph"]["host_enqueue_ms"]
         if cpu:
             line["cpu_baseline"] = cpu
         emit(line)
