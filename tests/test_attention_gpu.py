@@ -8,7 +8,7 @@ import torch
 
 from oracle import ref_cpu
 from oracle.fixture_recipe import seeded, seeded_params
-from util import assert_close, load_golden, weights_of
+from util import rel_err, assert_close, load_golden, weights_of
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -122,6 +122,47 @@ def test_core_softmax_spike(device):
     o_ref = ref_cpu.attention_core(q, k, v, D ** -0.5)
     o = ops.attention(q.to(device), k.to(device), v.to(device), D ** -0.5)
     assert_close(o, o_ref, TOL, "o")
+
+
+@pytest.mark.parametrize("D", [64, 32, 128])
+def test_lazy_reference_moves_in_every_tile(device, backward_path, D):
+    """The unmasked forwards keep a LAZY softmax reference (it moves only when a row's tile maximum passes it by 2^8,
+    csrc/attn_fwd.hip attn_fwd_plain_kernel): scores that climb steeply along the keys force the move -- the rescale
+    branch and the rewrite of the reference held in the MFMA accumulators -- in every tile, for some rows by much more
+    than the threshold, for others by less (no move: p up to 2^8).  Ragged sizes, so the peeled last tile is exercised
+    too; outputs and all gradients against the oracle, whose statistics are the true maxima."""
+    from amk import ops
+
+    B, H, I, J = 2, 2, 70, 333
+    q = seeded((B, H, I, D), 71)
+    k = seeded((B, H, J, D), 72) * 0.3
+    v = seeded((B, H, J, D), 73)
+    cot = seeded((B, H, I, D), 74)
+    u = torch.nn.functional.normalize(seeded((D,), 75), dim=0)
+    # a STAIRCASE, one step per 64-key tile: the scores climb from tile to tile (the reference has to move) but stay
+    # diffuse inside a tile, so the softmax does not collapse onto one key (a one-hot row makes dP - delta cancel
+    # catastrophically in any f32 backward, the reference's included)
+    ramp = (torch.arange(J) // 64).float().view(1, 1, J, 1) / (J // 64)
+    k = k + ramp * u * 90.0                              # q . k grows with the key tile along u ...
+    q = q + u * torch.linspace(0.0, 6.0, I).view(1, 1, I, 1)   # ... by an amount that differs from row to row
+    scale = D ** -0.5
+    # (the oracle in float64 here: at |s| ~ 100 an f32 oracle's own rounding of s is as large as the kernel's)
+    qc, kc, vc = (t.double().requires_grad_(True) for t in (q, k, v))
+    o_ref = ref_cpu.attention_core(qc, kc, vc, scale)
+    g_ref = [g.float() for g in torch.autograd.grad((o_ref * cot.double()).sum(), [qc, kc, vc])]
+    o_ref = o_ref.detach().float()
+    s = torch.einsum("bhid,bhjd->bhij", q, k) * scale * 1.4426950408889634
+    climb = float((s[..., -1] - s[..., 0]).abs().max())
+    assert climb > 64.0, climb                               # many times the 2^8 threshold across the sequence
+    qd, kd, vd = (t.to(device).requires_grad_(True) for t in (q, k, v))
+    o = ops.attention(qd, kd, vd, scale)
+    g = torch.autograd.grad((o * cot.to(device)).sum(), [qd, kd, vd])
+    assert_close(o, o_ref, TOL, "o")
+    # gradients: scores of magnitude ~100 in the log2 domain carry an f32 rounding of ~1e-5 each, which the backward's
+    # P (dP - delta) and the long k rows (|k| ~ 90) amplify: 1-4e-4 against float64 for this library's kernels before and
+    # after the lazy reference alike (AMK_ATTN_FWD_PLAIN=0) -- the input's conditioning, not the forward under test
+    for name, a, b in zip(("dq", "dk", "dv"), g, g_ref):
+        assert rel_err(a, b) < 1e-3, (name, rel_err(a, b))
 
 
 @pytest.mark.parametrize(
