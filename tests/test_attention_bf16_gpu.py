@@ -52,6 +52,24 @@ def test_bf16_core_forward_backward(device, B, H, I, J):
     assert torch.equal(dq, dq2) and torch.equal(dkv, dkv2)
 
 
+def test_bf16_lazy_reference_moves(device):
+    """Scores that climb by a step per 64-key tile: the unmasked bf16 forward's lazy softmax reference has to move in every
+    tile (the rescale branch), ragged sizes; against f32 on the bf16-rounded operands."""
+    from amk import ops
+
+    B, H, I, J, D = 2, 2, 70, 333, 64
+    u = torch.nn.functional.normalize(seeded((D,), 75), dim=0)
+    q = seeded((B, I, H, D), 71) + u * torch.linspace(0.0, 4.0, I).view(1, I, 1, 1)
+    k = seeded((B, J, H, D), 72) * 0.3 + ((torch.arange(J) // 64).float() / (J // 64)).view(1, J, 1, 1) * u * 60.0
+    v = seeded((B, J, H, D), 73)
+    q2 = q.reshape(B, I, H * D).bfloat16()
+    kv2 = torch.stack([k, v], dim=2).reshape(B, J, 2 * H * D).bfloat16()
+    qr, kvr = q2.float(), kv2.float().view(B, J, 2, H, D)
+    o_ref = _core_ref(qr.view(B, I, H, D).permute(0, 2, 1, 3), kvr[:, :, 0].permute(0, 2, 1, 3), kvr[:, :, 1].permute(0, 2, 1, 3), D ** -0.5)
+    o = ops.attention_fused_kv(q2.to(device), kv2.to(device), H, D, D ** -0.5)
+    assert rel_err(o.float(), o_ref.permute(0, 2, 1, 3).reshape(B, I, H * D)) < 5e-3
+
+
 def _masked_ref(q, k, v, scale, key_mask, causal_mask):
     """models/softmax_attention.py:62-76 in f32 on (B,H,T,D) tensors: masked_fill(-1e9), context_mask True = keep,
     causal_mask True = masked."""
