@@ -9,6 +9,7 @@ import os
 import weakref
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import lib as _lib
 
@@ -253,6 +254,7 @@ class _AttnCore(torch.autograd.Function):
         return o
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, d_o):
         q, k, v, o, stats, key_mask, causal_mask, scores = ctx.saved_tensors
@@ -288,6 +290,7 @@ class _AttnFusedKV(torch.autograd.Function):
         return o.permute(0, 2, 1, 3).reshape(B, I, H * D)
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, d_o2):
         q, k, v, o, stats, key_mask, causal_mask, scores = ctx.saved_tensors
@@ -338,6 +341,7 @@ class _AttnFusedKVBF16(torch.autograd.Function):
         return o2
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, d_o2):
         q2, kv2, o2, stats, key_mask, causal_mask = ctx.saved_tensors
@@ -445,6 +449,7 @@ class _VQLookup(torch.autograd.Function):
         return out.view(z.shape), idx_v, loss
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, g_out, _g_idx, g_loss):
         zf, cb, zn, zq, idx = ctx.saved_tensors
@@ -664,6 +669,7 @@ class _RoutedLinear(torch.autograd.Function):
         return out, r["ids"]
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, d_out, _d_ids):
         if d_out is None:
@@ -780,6 +786,7 @@ class _SharedRowExperts(torch.autograd.Function):
         return out, ids
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, d_out, _d_ids):
         if d_out is None:
@@ -834,6 +841,7 @@ class _SummedExperts(torch.autograd.Function):
         return out, ids
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, d_out, _d_ids):
         if d_out is None:
@@ -899,6 +907,7 @@ class _AgentAttn(torch.autograd.Function):
         return o.permute(0, 2, 1, 3).reshape(B, T, H * D)
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, d_o2):
         qkv2, cw, agents, vagent, stats1 = ctx.saved_tensors
@@ -987,6 +996,7 @@ class _SwiGLUBF16(torch.autograd.Function):
         return out.view(*ab.shape[:-1], H)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, d_out):
         (ab2,) = ctx.saved_tensors
         M, H2 = ab2.shape
@@ -1077,6 +1087,7 @@ class _LayerNorm(torch.autograd.Function):
         return y.view(x.shape)
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, dy):
         x2, w, mean, rstd = ctx.saved_tensors
@@ -1110,6 +1121,7 @@ class _AddLayerNorm(torch.autograd.Function):
         return h.view(x.shape), y.view(x.shape)
 
     @staticmethod
+    @once_differentiable
     @_amp_bwd
     def backward(ctx, dh_in, dy):
         h, w, mean, rstd = ctx.saved_tensors
@@ -1155,6 +1167,7 @@ class _AddLayerNormMixed(torch.autograd.Function):
         return hs.view(x.shape), y.view(x.shape)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dh_in, dy):
         h, w, mean, rstd = ctx.saved_tensors
         shape, xb, has_res = ctx.cfg
@@ -1228,6 +1241,7 @@ class _BiasLinear(torch.autograd.Function):
         return torch.nn.functional.linear(x, weight, bias)
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
@@ -1288,6 +1302,7 @@ class _LinearX6(torch.autograd.Function):
         return gemm_x6_nt(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         x2, weight = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, dy.shape[-1])
@@ -1371,6 +1386,7 @@ class _DenseLinear(torch.autograd.Function):
         return dense.gemm_nt(x2, weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         from . import dense
 
@@ -1423,6 +1439,7 @@ class _DenseLinear2(torch.autograd.Function):
         return a.view(*x.shape[:-1], wa.shape[0]), b.view(*x.shape[:-1], wb.shape[0])
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, da, db_):
         from . import dense
 
@@ -1465,6 +1482,7 @@ class _SwiGLUFFN(torch.autograd.Function):
         return out.view(*x.shape[:-1], w3.shape[0])
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dout):
         from . import dense
 
@@ -1505,6 +1523,7 @@ class _LinearMixed(torch.autograd.Function):
         return torch.nn.functional.linear(x16, w16, _w16(bias))
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         from . import dense
 
@@ -1562,6 +1581,7 @@ class _SwiGLUFFNMixed(torch.autograd.Function):
         return y.view(*x.shape[:-1], w3.shape[0])
 
     @staticmethod
+    @once_differentiable
     def backward(ctx, dy):
         from . import dense
 
