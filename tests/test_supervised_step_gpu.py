@@ -347,3 +347,18 @@ def test_accumulated_step_captured_as_one_graph(device):
             assert torch.equal(a, b)
     finally:
         ops.DETERMINISTIC_ATTENTION_BACKWARD = old
+
+
+def test_classifier_step_learns(device):
+    """Forty AdamW steps of ClassifierTrainStep on eight fixed images: the reduced ViTMoE memorises them (the cross-entropy
+    falls from ~ln 10 to well under 1) -- router, expert GEMMs, SwitchHead, schedule and optimizer working together."""
+    from amk.models import ViTMoE
+    from amk.train import ClassifierTrainStep
+
+    torch.manual_seed(0)
+    model = ViTMoE(**SMALL_MOE).to(device)
+    ts = ClassifierTrainStep(model, lr=2e-3, warmup_steps=3, total_steps=200, max_grad_norm=1.0, bucket_bytes=256 << 10)
+    imgs, labels = _moe_batch(device)
+    losses = [float(ts.step(imgs, labels)) for _ in range(40)]
+    assert all(l == l for l in losses)
+    assert losses[0] > 1.8 and losses[-1] < 0.7 * losses[0], (losses[0], losses[-1])
