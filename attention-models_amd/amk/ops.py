@@ -153,7 +153,10 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=False):
     x6 = ATTENTION_FORWARD == "bf16x6" and D == 64  # head dims 32 / 128 run the plain f32 kernels
     ws = torch.empty((L.amk_attn_fwd_x6_ws_bytes(B, H, J),), device=q.device, dtype=torch.uint8) if x6 else None
     scores = None
-    if (keep_scores and D == 64 and not x6 and ATTENTION_KEEP_SCORES
+    # (head dims 32 / 128: the score-keeping forward exists without masks; their one-pass backward takes atomics only)
+    det = DETERMINISTIC_ATTENTION_BACKWARD or torch.are_deterministic_algorithms_enabled()
+    keepable = D == 64 or (D in (32, 128) and key_mask is None and causal_mask is None and not det)
+    if (keep_scores and keepable and not x6 and ATTENTION_KEEP_SCORES
             and not ATTENTION_BACKWARD_TWO_KERNEL):
         nbytes = L.amk_attn_scores_bytes(B, H, I, J)
         if nbytes <= ATTENTION_KEEP_SCORES_MAX_BYTES and _kept_scores_bytes[0] + nbytes <= _keep_budget(q.device):
@@ -204,6 +207,8 @@ def _attn_backward(q, k, v, o, stats, d_o, dq, dk, dv, key_mask, causal_mask, sc
     if not stages & 8:
         scores = None
     B, H, I, D = q.shape
+    if D != 64 and stages & 64:
+        scores = None   # head dims 32 / 128 under the reproducible mode: the two recompute kernels (no kept scores)
     J = k.shape[2]
     d_o = _as_kernel_view(d_o)
     L = _lib.load()

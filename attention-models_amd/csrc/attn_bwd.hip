@@ -393,7 +393,8 @@ static int attn_bwd_impl(const float* scores, const float* q, const float* k, co
   AMK_CHECK_ARG(q && k && v && o && stats && d_o && dq && dk && dv && delta_ws, "amk_attn_bwd: null tensor pointer");
   AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_bwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
   AMK_CHECK_SUPPORTED(Dh == D || attn_gen_supported(Dh), "amk_attn_bwd: head dim %d not supported (32, 64, 128)", Dh);
-  AMK_CHECK_SUPPORTED(Dh == D || !scores, "amk_attn_bwd_kept: kept scores exist for head dim %d only", D);
+  AMK_CHECK_SUPPORTED(Dh == D || !scores || !(stages & AMK_ATTN_BWD_DQ_REPRO),
+                      "amk_attn_bwd_kept: kept scores with the reproducible dq exist for head dim %d only", D);
   BwdParams p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.stats = stats; p.d_o = d_o;
   p.dq = dq; p.dk = dk; p.dv = dv; p.delta = delta_ws;
@@ -422,7 +423,17 @@ static int attn_bwd_impl(const float* scores, const float* q, const float* k, co
                       "amk_attn_bwd: one (batch, head) slab must span < 2 GiB");
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (Dh != D) {
-    launch_attn_bwd_gen(p, Dh, stages, st);
+    // head dims 32 / 128: the one-pass kernel of attn_bwd_fused_gen.hip (dq by atomics) when FUSED is asked for and the
+    // layout allows it, else the two recompute kernels of attn_generic.hip (always for the reproducible dq)
+    if (stages & AMK_ATTN_BWD_FUSED) {
+      if (stages & AMK_ATTN_BWD_DELTA) launch_attn_bwd_gen(p, Dh, AMK_ATTN_BWD_DELTA, st);
+      if (!launch_attn_bwd_fused_gen(p, Dh, st)) {
+        AMK_CHECK_SUPPORTED(!scores, "amk_attn_bwd_kept: the one-pass kernel could not run (dq layout) and the recompute kernels do not read kept scores");
+        launch_attn_bwd_gen(p, Dh, AMK_ATTN_BWD_DKDV | AMK_ATTN_BWD_DQ, st);
+      }
+    } else {
+      launch_attn_bwd_gen(p, Dh, stages, st);
+    }
     AMK_CHECK_LAUNCH("amk_attn_bwd");
     return AMK_OK;
   }

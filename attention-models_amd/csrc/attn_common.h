@@ -130,5 +130,7 @@ int fused_keys_per_wg(int J, int keys_per_wg);
 bool attn_gen_supported(int Dh);
 void launch_attn_fwd_gen(const FwdParams& p, int Dh, int64_t nwg, hipStream_t st);
 void launch_attn_bwd_gen(const BwdParams& p, int Dh, int stages, hipStream_t st);
+// attn_bwd_fused_gen.hip: the one-pass backward for head dims 32 / 128 (dq by atomics); false = nothing launched
+bool launch_attn_bwd_fused_gen(const BwdParams& p, int Dh, hipStream_t st);
 
 }  // namespace amk_attn

@@ -539,7 +539,9 @@ static int attn_fwd_impl(void* x6_ws, bool x6, float* scores, const float* q, co
   AMK_CHECK_ARG(q && k && v && o && stats, "amk_attn_fwd: null tensor pointer");
   AMK_CHECK_ARG(B > 0 && H > 0 && I > 0 && J > 0, "amk_attn_fwd: non-positive size B=%d H=%d I=%d J=%d", B, H, I, J);
   AMK_CHECK_SUPPORTED(Dh == D || attn_gen_supported(Dh), "amk_attn_fwd: head dim %d not supported (32, 64, 128)", Dh);
-  AMK_CHECK_SUPPORTED(Dh == D || (!x6 && !scores), "amk_attn_fwd: the split-bf16 and score-keeping forwards are built for head dim %d", D);
+  AMK_CHECK_SUPPORTED(Dh == D || !x6, "amk_attn_fwd_x6: the split-bf16 forward is built for head dim %d", D);
+  AMK_CHECK_SUPPORTED(Dh == D || !scores || (!key_mask && !causal_mask),
+                      "amk_attn_fwd_keep: for head dims 32 / 128 the score-keeping forward exists without masks only");
   FwdParams p;
   p.q = q; p.k = k; p.v = v; p.o = o; p.stats = stats;
   p.key_mask = key_mask; p.causal_mask = causal_mask;

@@ -212,7 +212,9 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_kernel(Fw
 // leave as the statistics; the recompute backward forms exp2(S - m_ref) / l, the same P.
 __device__ __forceinline__ float gmax3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
 
-template <int DH>
+// KEEP: the raw scores also leave for the one-pass backward (ScoreTiles, as amk_attn_fwd_keep for head dim 64); that form
+// forms its S^T chains from zero and subtracts the reference afterwards (the backward needs the raw numbers).
+template <int DH, bool KEEP>
 __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_plain_kernel(FwdParams p) {
   using G = GenGeom<DH>;
   constexpr int HD = G::HD, LS = G::LS, NT = G::NT, TL = G::TL, NS = G::NS;
@@ -268,6 +270,10 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_plain_ker
   float mref = 0.f, l_run = 0.f;
   const int ntile = (p.J + TL - 1) / TL;
   const int nfull = p.J / TL;
+  const ScoreTiles stl(p.I, p.J);
+  const int64_t sc_kstep = (int64_t)stl.nqt * 1024;  // floats between consecutive 32-key blocks
+  float* sc_ptr = nullptr;
+  if (KEEP) sc_ptr = p.scores + ((int64_t)bh * stl.nkb * stl.nqt + (qb * NWAVE + wave)) * 1024 + 4 * hf * 32 + ln;
 
   auto tile = [&](const int t, auto ragged_c) {
     constexpr bool RAGGED = decltype(ragged_c)::value;
@@ -279,7 +285,7 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_plain_ker
     f32x16 s[NS];
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
-      s[u] = negm;
+      s[u] = KEEP ? zero16() : negm;
       const float* kr = &Ks[(32 * u + ln) * LS + HD * hf];
       float4 a = ld4(kr);
 #pragma unroll
@@ -289,6 +295,14 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_plain_ker
 #pragma unroll
         for (int e = 0; e < 4; ++e) s[u] = mfma32(f4(a, e), qreg[4 * s4 + e], s[u]);
         a = nx;
+      }
+    }
+    if (KEEP) {
+#pragma unroll
+      for (int u = 0; u < NS; ++u) {
+        float* t0 = sc_ptr + (int64_t)(NS * t + u) * sc_kstep;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(s[u][r], t0 + acc_row(r, 0) * 32);
       }
     }
     if (RAGGED) {
@@ -306,6 +320,7 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_plain_ker
 #pragma unroll
       for (int r = 0; r < 16; r += 2) mx = gmax3(mx, s[u][r], s[u][r + 1]);
     mx = __builtin_fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (KEEP) mx -= mref;
     if (t == 0 || __any(mx > TAU)) {   // rare after the first tile
       const float d = t == 0 ? mx : __builtin_fmaxf(mx, 0.f);
       if (t != 0) {
@@ -317,18 +332,20 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_fwd_gen_plain_ker
           for (int r = 0; r < 16; ++r) o[n][r] *= alpha;
       }
       mref += d;
+      if (!KEEP) {
 #pragma unroll
-      for (int u = 0; u < NS; ++u)
+        for (int u = 0; u < NS; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[u][r] -= d;
+          for (int r = 0; r < 16; ++r) s[u][r] -= d;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) negm[r] = -mref;
+        for (int r = 0; r < 16; ++r) negm[r] = -mref;
+      }
     }
     f32x2 ls = {0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NS; ++u) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[u][r] = __builtin_amdgcn_exp2f(s[u][r]);
+      for (int r = 0; r < 16; ++r) s[u][r] = __builtin_amdgcn_exp2f(KEEP ? s[u][r] - mref : s[u][r]);
 #pragma unroll
       for (int r = 0; r < 16; r += 2) ls += (f32x2){s[u][r], s[u][r + 1]};
     }
@@ -683,7 +700,8 @@ __global__ __launch_bounds__(WG, (DH <= 32 ? 2 : 1)) void attn_bwd_dkdv_gen_kern
 template <int DH>
 static void launch_fwd_gen(const FwdParams& p, int64_t nwg, hipStream_t st) {
   if (p.causal_mask) hipLaunchKernelGGL((attn_fwd_gen_kernel<DH, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
-  else if (!p.key_mask) hipLaunchKernelGGL((attn_fwd_gen_plain_kernel<DH>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
+  else if (!p.key_mask && p.scores) hipLaunchKernelGGL((attn_fwd_gen_plain_kernel<DH, true>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
+  else if (!p.key_mask) hipLaunchKernelGGL((attn_fwd_gen_plain_kernel<DH, false>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
   else hipLaunchKernelGGL((attn_fwd_gen_kernel<DH, false>), dim3((unsigned)nwg), dim3(WG), 0, st, p);
 }
 

@@ -149,15 +149,22 @@ def kernel_rooflines(B, dev, iters):
         mkg = lambda: torch.randn(B, T, Hg, Dg, generator=g).to(dev).permute(0, 2, 1, 3)
         qg, kg, vg, dog = mkg(), mkg(), mkg(), mkg()
         sg = Dg ** -0.5
-        qg, kg, vg, og, stg, _ = ops._attn_forward(qg, kg, vg, None, None, sg)
+        qg, kg, vg, og, stg, scg = ops._attn_forward(qg, kg, vg, None, None, sg, keep_scores=True)
         dqg, dkg, dvg = (torch.empty_like(qg) for _ in range(3))
         coreg = 4.0 * B * Hg * T * T * Dg
         t = time_launches(lambda: ops._attn_forward(qg, kg, vg, None, None, sg), iters)
         out.append(dict(kernel=f"attn_fwd_gen_kernel<{Dg}>", launches_per_step=0, avg_ms=t * 1e3, flop=coreg,
-                        note=f"4*B*h*I*J*d at head dim {Dg}, {Hg} heads"))
-        t = time_launches(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg), iters)
+                        note=f"4*B*h*I*J*d at head dim {Dg}, {Hg} heads (unmasked: attn_fwd_gen_plain_kernel)"))
+        if scg is not None:
+            t = time_launches(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=9, scores=scg), iters)
+            out.append(dict(kernel=f"attn_bwd_fused_gen_kernel<{Dg}>(kept scores) + delta", launches_per_step=0, avg_ms=t * 1e3,
+                            flop=2 * coreg, note="8*B*h*I*J*d: the one-pass backward of csrc/attn_bwd_fused_gen.hip (four products)"))
+        t = time_launches(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=9), iters)
+        out.append(dict(kernel=f"attn_bwd_fused_gen_kernel<{Dg}> + delta", launches_per_step=0, avg_ms=t * 1e3,
+                        flop=2 * coreg, note="8*B*h*I*J*d credited (five products: recomputed S not credited)"))
+        t = time_launches(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=7), iters)
         out.append(dict(kernel=f"attn_bwd_gen_kernels<{Dg}> (delta + dkdv + dq)", launches_per_step=0, avg_ms=t * 1e3,
-                        flop=2 * coreg, note="8*B*h*I*J*d credited (recomputed S and dP not credited)"))
+                        flop=2 * coreg, note="8*B*h*I*J*d credited (the reproducible recompute pair: seven products)"))
     for r in out:
         r["tflops"] = r["flop"] / (r["avg_ms"] * 1e-3) / 1e12
         r["frac_of_f32_mfma_peak"] = r["tflops"] / F32_MFMA_PEAK_TFLOPS

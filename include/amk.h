@@ -65,9 +65,10 @@ const char* amk_last_error(void);
  * the (B,T,h*D) projection outputs are consumed in place (st = h*D, sh = D) as
  * well as (B,h,T,D) tensors (sh = T*D, st = D).  k and v likewise with J rows.
  * key_mask: uint8 (B,J) contiguous or NULL; causal_mask: uint8 (I,J) contiguous
- * or NULL.  stats: (B,H,I,2) contiguous.  D is 32, 64 or 128 (64: the tuned kernels, the split-bf16
- * forward, kept scores and the one-pass backward; 32 / 128: the generic forward and the two
- * reproducible backward kernels of csrc/attn_generic.hip).
+ * or NULL.  stats: (B,H,I,2) contiguous.  D is 32, 64 or 128 (64: the tuned kernels and the split-bf16
+ * forward; 32 / 128: csrc/attn_generic.hip -- forward, with kept scores when there is no mask -- and
+ * csrc/attn_bwd_fused_gen.hip, the one-pass backward with dq by atomics; the reproducible backward of
+ * those head dims is the two recompute kernels of csrc/attn_generic.hip).
  * -------------------------------------------------------------------------- */
 int amk_attn_fwd(const float* q, const float* k, const float* v, float* o, float* stats,
                  const uint8_t* key_mask, const uint8_t* causal_mask,
