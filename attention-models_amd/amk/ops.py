@@ -153,9 +153,11 @@ def _attn_forward(q, k, v, key_mask, causal_mask, scale, keep_scores=False):
     x6 = ATTENTION_FORWARD == "bf16x6" and D == 64  # head dims 32 / 128 run the plain f32 kernels
     ws = torch.empty((L.amk_attn_fwd_x6_ws_bytes(B, H, J),), device=q.device, dtype=torch.uint8) if x6 else None
     scores = None
-    # (head dims 32 / 128: the score-keeping forward exists without masks; their one-pass backward takes atomics only)
+    # (head dim 128: the score-keeping forward exists without masks, and its one-pass backward takes atomics only.  Head dim
+    # 32 has both too, but recomputing wins there -- 0.618 against 0.609 of the f32 MFMA peak: the scores are 4 bytes per
+    # (query, key) against only 32 multiply-adds, 2.1 GB per launch at the benchmark shape -- so its scores are not kept)
     det = DETERMINISTIC_ATTENTION_BACKWARD or torch.are_deterministic_algorithms_enabled()
-    keepable = D == 64 or (D in (32, 128) and key_mask is None and causal_mask is None and not det)
+    keepable = D == 64 or (D == 128 and key_mask is None and causal_mask is None and not det)
     if (keep_scores and keepable and not x6 and ATTENTION_KEEP_SCORES
             and not ATTENTION_BACKWARD_TWO_KERNEL):
         nbytes = L.amk_attn_scores_bytes(B, H, I, J)

@@ -3,8 +3,8 @@
 // accumulators, query tiles of 32, S read back from the forward's kept score tiles (or recomputed), dS through LDS once and
 // dQ = dS K on v_mfma_f32_16x16x4_f32 added to dq by f32 atomics -- with the head dim as a template parameter.
 //
-//   DH = 32 : NW = 8 waves (256 keys per workgroup, two waves per SIMD); the 32 x 32 dQ tile is four 16 x 16 blocks, so two
-//             waves share a block and split the workgroup's keys between them (both add their halves atomically);
+//   DH = 32 : NW = 8 waves (256 keys per workgroup, two waves per SIMD) and query tiles of 64 (two 32-query sub-tiles per
+//             barrier pair): the 64 x 32 dQ tile is eight 16 x 16 blocks, one per wave;
 //   DH = 128: NW = 4 waves (128 keys per workgroup) at ONE wave per SIMD with the 512-register file: eight 32 x 32
 //             accumulators for dK^T / dV^T alone are 128 registers; the 32 x 128 dQ tile is sixteen blocks, four per wave.
 //
@@ -17,10 +17,13 @@ namespace amk_attn {
 
 namespace {
 
-constexpr int GTQ = 32;   // queries per tile
-
-template <int DH, int NW>
+// QS: 32-query sub-tiles per query tile (one barrier pair and one q / dO staging pass per TILE).  Head dim 32 uses 2: its
+// sub-tile carries half the MFMA work of head dim 64 over the same softmax arithmetic, LDS round trip and barriers, its
+// staging pass covers 64 rows anyway (512 threads x 16 B), and with 64 queries the dQ tile is eight 16 x 16 blocks -- one
+// per wave, no split of the keys between waves.
+template <int DH, int NW, int QS>
 struct FGeom {
+  static constexpr int GTQ = 32 * QS;            // queries per tile
   static constexpr int NT = 64 * NW;
   static constexpr int KB = 32 * NW;             // keys per workgroup
   static constexpr int HD = DH / 2;              // k-extent owned by one half-wave
@@ -34,7 +37,8 @@ struct FGeom {
   static constexpr int DS_STRIDE = KB + 4;
   static constexpr int KPG = KB / 4;             // keys per k-group of the 16x16x4 product
   static constexpr int NCB = DH / 16;            // 16-wide column blocks of the dQ tile
-  static constexpr int PAIRS = NW / 2;           // waves per query half
+  static constexpr int NQB = 2 * QS;             // 16-query row blocks of the dQ tile
+  static constexpr int PAIRS = NW / NQB;         // waves per row block
   static constexpr int CBW = NCB / PAIRS > 0 ? NCB / PAIRS : 1;   // column blocks per wave
   static constexpr int KS = PAIRS / NCB > 0 ? PAIRS / NCB : 1;    // waves sharing a block (they split the keys)
   static constexpr int LDS_FLOATS = 2 * QROWS * LS + KB * LS + GTQ * DS_STRIDE + 4 * GTQ;
@@ -44,9 +48,9 @@ __device__ __forceinline__ f32x4 gmfma16(float a, float b, f32x4 c) { return __b
 
 // rows [row0, row0 + nrows) x DH floats of one (batch, head) operand through a range-checked descriptor; thread ->
 // (row = tid / F4R + RP * pass, 16 B at column 4 * (tid % F4R)); rows the tile does not have get an offset past the range
-template <int DH, int NW>
+template <int DH, int NW, int QS>
 struct FStager {
-  using G = FGeom<DH, NW>;
+  using G = FGeom<DH, NW, QS>;
   __amdgpu_buffer_rsrc_t rsrc;
   int64_t st;
   int nrows_total;
@@ -63,11 +67,11 @@ struct FStager {
   }
 };
 
-template <int DH, int NW, bool KEPT, bool CAUSAL>
+template <int DH, int NW, int QS, bool KEPT, bool CAUSAL>
 __global__ __launch_bounds__(64 * NW, (DH >= 128 ? 1 : 2)) void attn_bwd_fused_gen_kernel(BwdParams p) {
-  using G = FGeom<DH, NW>;
+  using G = FGeom<DH, NW, QS>;
   constexpr int KB = G::KB, HD = G::HD, LS = G::LS, NTILE = G::NTILE, DS_STRIDE = G::DS_STRIDE, KPG = G::KPG;
-  constexpr int TQ = GTQ;
+  constexpr int TQ = G::GTQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Qs = smem;                           // [QROWS][LS]  (q * scale * log2 e)
   float* Gs = Qs + G::QROWS * LS;             // [QROWS][LS]  dO
@@ -106,15 +110,17 @@ __global__ __launch_bounds__(64 * NW, (DH >= 128 ? 1 : 2)) void attn_bwd_fused_g
   else if (p.key_mask && p.key_mask[(int64_t)b * p.J + kj] == 0) kfill = AMK_FILL_MASKED;
   const bool plain = !CAUSAL && __all(kfill == 0.f);  // wave-uniform
   const uint8_t* cm_col = CAUSAL ? p.causal_mask + min(kj, p.J - 1) : nullptr;
-  unsigned cm_raw[16];
+  unsigned cm_raw[QS][16];
   auto load_cmask = [&](int i0) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) cm_raw[r] = cm_col[(int64_t)min(i0 + acc_row(r, hf), p.I - 1) * p.J];
+    for (int u = 0; u < QS; ++u)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cm_raw[u][r] = cm_col[(int64_t)min(i0 + 32 * u + acc_row(r, hf), p.I - 1) * p.J];
   };
 
   // K rows of the whole workgroup -> LDS once
   {
-    FStager<DH, NW> kl;
+    FStager<DH, NW, QS> kl;
     kl.init(kbase, p.ks.st, p.J);
     const int have = min(KB, p.J - kb * KB);
     constexpr int HALFP = G::KNP >= 2 ? G::KNP / 2 : 1;
@@ -146,15 +152,17 @@ __global__ __launch_bounds__(64 * NW, (DH >= 128 ? 1 : 2)) void attn_bwd_fused_g
     sc_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)tiles, 0, kb32 < stl.nkb ? stl.nqt * 4096 : 0, 0x00020000);
     sc_voff = ln * 128 + hf * 16;
   }
-  float4 sk[4];
-  auto load_scores = [&](int qt) {
+  float4 sk[QS][4];
+  auto load_scores = [&](int qt) {   // qt: query TILE; its sub-tiles are consecutive 4-KiB score tiles
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-      sk[g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sc_rsrc, sc_voff + qt * 4096 + 32 * g, 0, 2));
+    for (int u = 0; u < QS; ++u)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        sk[u][g] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(sc_rsrc, sc_voff + (qt * QS + u) * 4096 + 32 * g, 0, 2));
   };
 
   float4 qst[G::QNP], gst[G::QNP];
-  FStager<DH, NW> qload, gload;
+  FStager<DH, NW, QS> qload, gload;
   qload.init(qbase, p.qs.st, p.I);
   gload.init(gbase, p.dos.st, p.I);
   float2 ml_raw = make_float2(0.f, 1.f);
@@ -197,8 +205,8 @@ __global__ __launch_bounds__(64 * NW, (DH >= 128 ? 1 : 2)) void attn_bwd_fused_g
 
   // dQ product geometry: 16x16x4 MFMA, lane = (column c = l & 15, k-group kg = l >> 4)
   const int c16 = lane & 15, kg = lane >> 4;
-  const int qhalf = wave & 1;
-  const int pr = wave >> 1;                                  // index among the waves of this query half
+  const int qhalf = wave % G::NQB;                           // which 16 of the tile's queries
+  const int pr = wave / G::NQB;                              // index among the waves of this row block
   const int colblk0 = G::KS > 1 ? pr % G::NCB : pr * G::CBW; // first 16-wide column block of this wave
   const int kpart = G::KS > 1 ? pr / G::NCB : 0;             // which part of the keys (waves sharing a block)
   constexpr int S4N = KPG / 4 / G::KS;                       // k-steps of 4 per wave
@@ -219,95 +227,101 @@ __global__ __launch_bounds__(64 * NW, (DH >= 128 ? 1 : 2)) void attn_bwd_fused_g
   for (int t = 0; t < ntile; ++t) {
     const int i0 = tile_of(t) * TQ;
 
-    // ---- S and dP for the tile's 32 queries x this wave's 32 keys (dP's chain starts from -delta)
-    f32x16 s = zero16(), dp;
+    // ---- per 32-query sub-tile: S and dP for its queries x this wave's 32 keys (dP's chain starts from -delta), P, dS,
+    //      dS -> LDS, dV^T / dK^T accumulation
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float4 d4 = ld4(&Ds[8 * g + 4 * hf]);
-      dp[4 * g + 0] = d4.x; dp[4 * g + 1] = d4.y; dp[4 * g + 2] = d4.z; dp[4 * g + 3] = d4.w;
-    }
-    {
-      const float* qr = &Qs[ln * LS + HD * hf];
-      const float* gr = &Gs[ln * LS + HD * hf];
-      const float* kr = &Kc[(32 * wave + ln) * LS + HD * hf];
+    for (int u = 0; u < QS; ++u) {
+      f32x16 s = zero16(), dp;
 #pragma unroll
-      for (int s4 = 0; s4 < HD / 4; ++s4) {
-        const float4 c = ld4(gr + 4 * s4);
-        if (!KEPT) {
-          const float4 a = ld4(qr + 4 * s4);
-          const float4 kk = ld4(kr + 4 * s4);
+      for (int g = 0; g < 4; ++g) {
+        const float4 d4 = ld4(&Ds[32 * u + 8 * g + 4 * hf]);
+        dp[4 * g + 0] = d4.x; dp[4 * g + 1] = d4.y; dp[4 * g + 2] = d4.z; dp[4 * g + 3] = d4.w;
+      }
+      {
+        const float* qr = &Qs[(32 * u + ln) * LS + HD * hf];
+        const float* gr = &Gs[(32 * u + ln) * LS + HD * hf];
+        const float* kr = &Kc[(32 * wave + ln) * LS + HD * hf];
+#pragma unroll
+        for (int s4 = 0; s4 < HD / 4; ++s4) {
+          const float4 c = ld4(gr + 4 * s4);
+          if (!KEPT) {
+            const float4 a = ld4(qr + 4 * s4);
+            const float4 kk = ld4(kr + 4 * s4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              s = mfma32(f4(a, e), f4(kk, e), s);
+              dp = mfma32(f4(c, e), vreg[4 * s4 + e], dp);
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dp = mfma32(f4(c, e), vreg[4 * s4 + e], dp);
+          }
+        }
+      }
+      if (KEPT) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          s[4 * g + 0] = sk[u][g].x; s[4 * g + 1] = sk[u][g].y; s[4 * g + 2] = sk[u][g].z; s[4 * g + 3] = sk[u][g].w;
+        }
+      }
+      // P and dS (register r of this lane is query 32 u + acc_row(r, hf))
+      if (plain) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 ml4 = ld4(&MLs[32 * u + 8 * g + 4 * hf]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            s = mfma32(f4(a, e), f4(kk, e), s);
-            dp = mfma32(f4(c, e), vreg[4 * s4 + e], dp);
+            const int r = 4 * g + e;
+            const float prb = __builtin_amdgcn_exp2f(s[r] - f4(ml4, e));
+            s[r] = prb;
+            dp[r] = prb * dp[r];
           }
-        } else {
+        }
+      } else {
+        unsigned cbits = 0xffffu;
+        if (CAUSAL) {
+          cbits = 0;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) dp = mfma32(f4(c, e), vreg[4 * s4 + e], dp);
+          for (int r = 0; r < 16; ++r) cbits |= (cm_raw[u][r] == 0 ? 1u : 0u) << r;
+        }
+        const float fillv = kfill != 0.f ? kfill : AMK_FILL_MASKED;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float4 m4 = ld4(&Ms[32 * u + 8 * g + 4 * hf]);
+          const float4 l4 = ld4(&Ls[32 * u + 8 * g + 4 * hf]);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            const bool filled = kfill != 0.f || !((cbits >> r) & 1u);
+            const float tt = filled ? fillv : s[r];
+            const float prb = __builtin_amdgcn_exp2f(tt - f4(m4, e)) * f4(l4, e);
+            s[r] = prb;
+            dp[r] = filled ? 0.f : prb * dp[r];
+          }
         }
       }
-    }
-    if (KEPT) {
+      // dS -> LDS as [query][key]
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        s[4 * g + 0] = sk[g].x; s[4 * g + 1] = sk[g].y; s[4 * g + 2] = sk[g].z; s[4 * g + 3] = sk[g].w;
-      }
-    }
-    // ---- P and dS (register r of this lane is query acc_row(r, hf))
-    if (plain) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 ml4 = ld4(&MLs[8 * g + 4 * hf]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const float prb = __builtin_amdgcn_exp2f(s[r] - f4(ml4, e));
-          s[r] = prb;
-          dp[r] = prb * dp[r];
+      for (int r = 0; r < 16; ++r) dSl[(32 * u + acc_row(r, hf)) * DS_STRIDE + 32 * wave + ln] = dp[r];
+      // the next tile's scores / mask bytes: requested HERE, ahead of the last sub-tile's dV / dK products (consumed after
+      // the next tile's dP product: three MFMA phases away; the last iteration re-reads its own tile, unused)
+      if (u == QS - 1) {
+        if (KEPT) {
+          load_scores(tile_of(min(t + 1, ntile - 1)));
+          __builtin_amdgcn_sched_barrier(0);
         }
+        if (CAUSAL) load_cmask(tile_of(min(t + 1, ntile - 1)) * TQ);
       }
-    } else {
-      unsigned cbits = 0xffffu;
-      if (CAUSAL) {
-        cbits = 0;
+      // dV^T += dO^T P ; dK^T += (q*scale*log2e)^T dS
 #pragma unroll
-        for (int r = 0; r < 16; ++r) cbits |= (cm_raw[r] == 0 ? 1u : 0u) << r;
-      }
-      const float fillv = kfill != 0.f ? kfill : AMK_FILL_MASKED;
+      for (int r = 0; r < 16; ++r) {
+        const float* gc = &Gs[(32 * u + acc_row(r, hf)) * LS + ln];
+        const float* qc = &Qs[(32 * u + acc_row(r, hf)) * LS + ln];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 m4 = ld4(&Ms[8 * g + 4 * hf]);
-        const float4 l4 = ld4(&Ls[8 * g + 4 * hf]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int r = 4 * g + e;
-          const bool filled = kfill != 0.f || !((cbits >> r) & 1u);
-          const float tt = filled ? fillv : s[r];
-          const float prb = __builtin_amdgcn_exp2f(tt - f4(m4, e)) * f4(l4, e);
-          s[r] = prb;
-          dp[r] = filled ? 0.f : prb * dp[r];
+        for (int n = 0; n < NTILE; ++n) {
+          dv[n] = mfma32(gc[32 * n], s[r], dv[n]);
+          dk[n] = mfma32(qc[32 * n], dp[r], dk[n]);
         }
-      }
-    }
-    // ---- dS -> LDS as [query][key]
-#pragma unroll
-    for (int r = 0; r < 16; ++r) dSl[acc_row(r, hf) * DS_STRIDE + 32 * wave + ln] = dp[r];
-
-    if (KEPT) {
-      load_scores(tile_of(min(t + 1, ntile - 1)));
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (CAUSAL) load_cmask(tile_of(min(t + 1, ntile - 1)) * TQ);
-
-    // ---- dV^T += dO^T P ; dK^T += (q*scale*log2e)^T dS
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float* gc = &Gs[acc_row(r, hf) * LS + ln];
-      const float* qc = &Qs[acc_row(r, hf) * LS + ln];
-#pragma unroll
-      for (int n = 0; n < NTILE; ++n) {
-        dv[n] = mfma32(gc[32 * n], s[r], dv[n]);
-        dk[n] = mfma32(qc[32 * n], dp[r], dk[n]);
       }
     }
     __syncthreads();  // every wave's dS columns are in LDS; the q / dO / stats tiles are dead
@@ -355,10 +369,10 @@ __global__ __launch_bounds__(64 * NW, (DH >= 128 ? 1 : 2)) void attn_bwd_fused_g
   }
 }
 
-template <int DH, int NW, bool KEPT, bool CAUSAL>
+template <int DH, int NW, int QS, bool KEPT, bool CAUSAL>
 bool launch_one(BwdParams p, hipStream_t st) {
-  using G = FGeom<DH, NW>;
-  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_gen_kernel<DH, NW, KEPT, CAUSAL>),
+  using G = FGeom<DH, NW, QS>;
+  static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_fused_gen_kernel<DH, NW, QS, KEPT, CAUSAL>),
                                                   hipFuncAttributeMaxDynamicSharedMemorySize,
                                                   G::LDS_FLOATS * (int)sizeof(float)) == hipSuccess;
   if (!attr_ok) return false;
@@ -366,14 +380,14 @@ bool launch_one(BwdParams p, hipStream_t st) {
   const int64_t ndq = (int64_t)p.B * p.I * p.H * DH;
   if (hipMemsetAsync(p.dq, 0, (size_t)ndq * sizeof(float), st) != hipSuccess) return false;
   const int64_t nk = (int64_t)p.B * p.H * p.nkblk;
-  hipLaunchKernelGGL((attn_bwd_fused_gen_kernel<DH, NW, KEPT, CAUSAL>), dim3((unsigned)nk), dim3(G::NT), G::LDS_FLOATS * sizeof(float), st, p);
+  hipLaunchKernelGGL((attn_bwd_fused_gen_kernel<DH, NW, QS, KEPT, CAUSAL>), dim3((unsigned)nk), dim3(G::NT), G::LDS_FLOATS * sizeof(float), st, p);
   return true;
 }
 
-template <int DH, int NW>
+template <int DH, int NW, int QS>
 bool launch_dh(const BwdParams& p, hipStream_t st) {
-  if (p.scores) return p.causal_mask ? launch_one<DH, NW, true, true>(p, st) : launch_one<DH, NW, true, false>(p, st);
-  return p.causal_mask ? launch_one<DH, NW, false, true>(p, st) : launch_one<DH, NW, false, false>(p, st);
+  if (p.scores) return p.causal_mask ? launch_one<DH, NW, QS, true, true>(p, st) : launch_one<DH, NW, QS, true, false>(p, st);
+  return p.causal_mask ? launch_one<DH, NW, QS, false, true>(p, st) : launch_one<DH, NW, QS, false, false>(p, st);
 }
 
 }  // namespace
@@ -383,8 +397,8 @@ bool launch_dh(const BwdParams& p, hipStream_t st) {
 bool launch_attn_bwd_fused_gen(const BwdParams& p, int Dh, hipStream_t st) {
   if (p.dq_part) return false;
   if (!(p.dqs.sh == Dh && p.dqs.st == (int64_t)p.H * Dh && p.dqs.sb == (int64_t)p.I * p.H * Dh)) return false;
-  if (Dh == 32) return launch_dh<32, 8>(p, st);
-  if (Dh == 128) return launch_dh<128, 4>(p, st);
+  if (Dh == 32) return launch_dh<32, 8, 2>(p, st);
+  if (Dh == 128) return launch_dh<128, 4, 1>(p, st);
   return false;
 }
 

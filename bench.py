@@ -149,7 +149,7 @@ def kernel_rooflines(B, dev, iters):
         mkg = lambda: torch.randn(B, T, Hg, Dg, generator=g).to(dev).permute(0, 2, 1, 3)
         qg, kg, vg, dog = mkg(), mkg(), mkg(), mkg()
         sg = Dg ** -0.5
-        qg, kg, vg, og, stg, scg = ops._attn_forward(qg, kg, vg, None, None, sg, keep_scores=True)
+        qg, kg, vg, og, stg, scg = ops._attn_forward(qg, kg, vg, None, None, sg, keep_scores=True)   # (kept for head dim 128 only)
         dqg, dkg, dvg = (torch.empty_like(qg) for _ in range(3))
         coreg = 4.0 * B * Hg * T * T * Dg
         t = time_launches(lambda: ops._attn_forward(qg, kg, vg, None, None, sg), iters)
