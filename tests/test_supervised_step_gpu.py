@@ -194,7 +194,7 @@ def test_captured_gan_step_with_collectives_replays_like_eager(device):
         dist.destroy_process_group()
 
 
-def _moe_two_rank_worker(rank, world, port, out_dir):
+def _moe_two_rank_worker(rank, world, port, out_dir, overlap=True):
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -214,7 +214,7 @@ def _moe_two_rank_worker(rank, world, port, out_dir):
         torch.manual_seed(30 + rank)           # different init per rank: the broadcast must fix it
         model = ViTMoE(**SMALL_MOE).to(dev)
         ts = ClassifierTrainStep(model, lr=1e-3, warmup_steps=1, total_steps=10, bucket_bytes=256 << 10,
-                                 accum_steps=1 if world > 1 else 2)
+                                 accum_steps=1 if world > 1 else 2, overlap=overlap)
         g = torch.Generator().manual_seed(6)
         imgs = torch.randn(3, 8, 3, 64, 64, generator=g).to(dev)
         labels = torch.randint(0, 10, (3, 8), generator=g).to(dev)
@@ -244,11 +244,14 @@ def _moe_two_rank_worker(rank, world, port, out_dir):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_classifier_step_on_reduced_vit_moe(device, tmp_path):
+@pytest.mark.parametrize("overlap", [True, False])
+def test_two_ranks_classifier_step_on_reduced_vit_moe(device, tmp_path, overlap):
+    """overlap=False: the all-reduces on the compute stream at bucket completion (the form bench.py captures for models with
+    little gradient traffic) -- same buckets, same order, same results."""
     import torch.multiprocessing as mp
 
-    mp.spawn(_moe_two_rank_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    mp.spawn(_moe_two_rank_worker, args=(1, 0, str(tmp_path)), nprocs=1, join=True)   # (fresh process: same start state)
+    mp.spawn(_moe_two_rank_worker, args=(2, _free_port(), str(tmp_path), overlap), nprocs=2, join=True)
+    mp.spawn(_moe_two_rank_worker, args=(1, 0, str(tmp_path), overlap), nprocs=1, join=True)   # (fresh process: same start state)
     r0 = torch.load(tmp_path / "moe_w2_r0.pt", weights_only=True)
     r1 = torch.load(tmp_path / "moe_w2_r1.pt", weights_only=True)
     one = torch.load(tmp_path / "moe_w1_r0.pt", weights_only=True)
