@@ -522,9 +522,9 @@ using namespace amk_attn;
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 // AMK_ATTN_FWD_PLAIN=0: unmasked calls go through the mask-capable kernel as well (A/B measurements)
-static bool getenv_plain() {
-  static const bool on = [] { const char* e = getenv("AMK_ATTN_FWD_PLAIN"); return !(e && e[0] == '0'); }();
-  return on;
+static bool getenv_plain() {   // (read per call: tools/ab_attn_fwd.py flips it inside one process)
+  const char* e = getenv("AMK_ATTN_FWD_PLAIN");
+  return !(e && e[0] == '0');
 }
 static bool strides_ok(const Strides& s) { return (s.sb % 4 == 0) && (s.st % 4 == 0) && (s.sh % 4 == 0); }
 

@@ -24,7 +24,6 @@
 //        codebook rows receive 2(zq - zn)/(N*C) through their own Jacobian by f32 atomics
 //        (one 128-B segment per row per wave-instruction: the full-rate shape).
 #include "amk_common.h"
-#include <stdlib.h>
 
 namespace amk_vq {
 
@@ -235,193 +234,6 @@ __global__ __launch_bounds__(256, (C <= 64 ? 2 : 1)) void vq_argmin_kernel(const
   }
 }
 
-// vq_argmin with TWO z rows per lane (round 4, codebook dims up to 64): a wave sweeps 64 rows, so a code fragment read from
-// LDS feeds two MFMAs (one per row block: two independent accumulator chains) -- 0.375 ds_read_b128 per MFMA instead of
-// 0.5 -- and a workgroup covers 256 rows.  Same arithmetic per (row, code) as vq_argmin_kernel, same tie rules: bit-identical
-// indices.  AMK_VQ_ROWS2=0 keeps the one-row kernel.
-template <int C>
-__global__ __launch_bounds__(256, 2) void vq_argmin2_kernel(const float* __restrict__ z, const float* __restrict__ en,
-                                                          const float* __restrict__ ee, int64_t N, int K, int nsplit,
-                                                          float* __restrict__ zn_out, float* __restrict__ pmin,
-                                                          int32_t* __restrict__ pidx) {
-  constexpr int HC = C / 2;       // k-extent owned by one half-wave
-  constexpr int CODES_LDS = codes_lds<C>();
-  constexpr int LS = C + 4;       // LDS row stride: conflict-free ds_read_b128 row reads
-  __shared__ __attribute__((aligned(16))) float smem[CODES_LDS * LS + CODES_LDS];
-  float* Es = smem;
-  float* EEs = smem + CODES_LDS * LS;
-
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int ln = lane & 31, hf = lane >> 5;
-
-  const int wg = xcd_remap(blockIdx.x, gridDim.x);
-  // (readfirstlane: the division runs on the vector unit; without it the loads through the slice's buffer
-  // descriptor below are wrapped in waterfall loops)
-  const int split = __builtin_amdgcn_readfirstlane(wg % nsplit);  // consecutive ids share the z rows, walk the slices
-  const int64_t rb = __builtin_amdgcn_readfirstlane(wg / nsplit);
-  constexpr int RB = 2;
-  const int64_t row0 = rb * (ROWS_WG * RB) + wave * (32 * RB) + ln;   // this lane's rows: row0 and row0 + 32
-
-  // zn^T operands: lane (row, half) holds zn[row][HC*half + s] of BOTH its rows
-  float zreg[RB][HC];
-#pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    const int64_t row = row0 + 32 * j;
-    const bool rvalid = row < N;
-    const float* zp = z + row * C + HC * hf;
-    float ss = 0.f;
-#pragma unroll
-    for (int s4 = 0; s4 < HC / 4; ++s4) {
-      const float4 t = rvalid ? ld4(zp + 4 * s4) : make_float4(0.f, 0.f, 0.f, 0.f);
-      zreg[j][4 * s4 + 0] = t.x; zreg[j][4 * s4 + 1] = t.y; zreg[j][4 * s4 + 2] = t.z; zreg[j][4 * s4 + 3] = t.w;
-      ss += t.x * t.x + t.y * t.y + t.z * t.z + t.w * t.w;
-    }
-    ss += __shfl_xor(ss, 32, 64);
-    const float denom = fmaxf(sqrtf(ss), EPS);
-#pragma unroll
-    for (int s = 0; s < HC; ++s) zreg[j][s] = zreg[j][s] / denom;
-    if (split == 0 && rvalid) {
-      float* op = zn_out + row * C + HC * hf;
-#pragma unroll
-      for (int s4 = 0; s4 < HC / 4; ++s4)
-        st4(op + 4 * s4, make_float4(zreg[j][4 * s4], zreg[j][4 * s4 + 1], zreg[j][4 * s4 + 2], zreg[j][4 * s4 + 3]));
-    }
-  }
-
-  const int kper = K / nsplit;          // codes in this slice (multiple of 32)
-  const int kbeg = split * kper;
-  const int ntile = (kper + CODES_LDS - 1) / CODES_LDS;
-
-  // staging: a tile is CODES_LDS*C CONTIGUOUS floats of the slice = (CODES_LDS*C/4) float4 over 256
-  // threads, fetched through a buffer descriptor that ends with the slice: rows past it read as zeros
-  // (hardware range check), so a tile costs NF4 loads and no compares, selects or 64-bit address math
-  // (every VALU instruction is paid against the f32 MFMA pipe).
-  constexpr int NF4 = CODES_LDS * C / 4 / 256;
-  const __amdgpu_buffer_rsrc_t en_rsrc =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(en + (int64_t)kbeg * C), 0, kper * C * 4, 0x00020000);
-  const __amdgpu_buffer_rsrc_t ee_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(ee + kbeg), 0, kper * 4, 0x00020000);
-  float4 est[NF4];
-  float eest = 0.f;
-  bool ee_ok = false;
-  auto prefetch = [&](int t) {
-    const int tile_off = t * CODES_LDS * C * 4;  // bytes; added to the VECTOR offset, the part the range check covers
-#pragma unroll
-    for (int ps = 0; ps < NF4; ++ps)
-      est[ps] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(en_rsrc, (tid + 256 * ps) * 16 + tile_off, 0, 0));
-    // one ee per code (the range check returns 0 past the slice; commit() puts the padding value in)
-    eest = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ee_rsrc, (tid & (CODES_LDS - 1)) * 4 + t * CODES_LDS * 4, 0, 0));
-    ee_ok = t * CODES_LDS + (tid & (CODES_LDS - 1)) < kper;
-  };
-  auto commit = [&]() {
-    // nothing that consumes the loads may be scheduled up to them (it would wait out the memory latency
-    // in front of a tile's MFMAs): the loads were issued a tile ago
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int ps = 0; ps < NF4; ++ps) {
-      const int f = tid + 256 * ps;
-      const int r = f / (C / 4), c4 = f % (C / 4);
-      st4(&Es[r * LS + 4 * c4], est[ps]);
-    }
-    // codes past the slice: ee = +inf -> score -inf, never chosen
-    if (tid < CODES_LDS) EEs[tid] = ee_ok ? -0.5f * eest : -INFINITY;
-  };
-
-  // vq.hip is compiled with -fno-honor-nans -mno-amdgpu-ieee (Makefile): fmaxf is then a bare
-  // v_max_f32 / v_max3_f32 with no canonicalising v_max(x, x) in front of it
-  auto vmax = [&](float a, float b) { return fmaxf(a, b); };
-  float best[RB];
-  int bbase[RB], bsub[RB];
-#pragma unroll
-  for (int j = 0; j < RB; ++j) { best[j] = -INFINITY; bbase[j] = kbeg; bsub[j] = 0; }
-  prefetch(0);
-  for (int t = 0; t < ntile; ++t) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (t + 1 < ntile) prefetch(t + 1);
-    const int c0 = kbeg + t * CODES_LDS;
-    const int nsub = min(CODES_LDS, kper - t * CODES_LDS) / 32;
-    // -ee/2 of this half-wave's 16 codes of sub-tile u, in accumulator order: the loads go
-    // straight into the registers the MFMA chain uses as its C operand
-    auto load_init = [&](int u) {
-      f32x16 a;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float4 n = ld4(&EEs[32 * u + 8 * g + 4 * hf]);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) a[4 * g + e] = f4(n, e);
-      }
-      return a;
-    };
-    struct AHead { float4 a0, a1; };  // first half of the A operand (codes) of a sub-tile
-    auto load_head = [&](int u) {
-      const float* er = &Es[(32 * u + ln) * LS + HC * hf];
-      return AHead{ld4(er), ld4(er + 4)};
-    };
-    auto subtile = [&](int u, const f32x16& init, const AHead& hd) {
-      const float* er = &Es[(32 * u + ln) * LS + HC * hf];
-      f32x16 acc[RB];
-#pragma unroll
-      for (int j = 0; j < RB; ++j) acc[j] = init;   // -ee/2 of the sub-tile's codes opens both rows' chains
-#pragma unroll
-      for (int s4 = 0; s4 < HC / 4; ++s4) {
-        const float4 a = s4 == 0 ? hd.a0 : (s4 == 1 ? hd.a1 : ld4(er + 4 * s4));
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-          for (int j = 0; j < RB; ++j) acc[j] = mfma32(f4(a, e), zreg[j][4 * s4 + e], acc[j]);   // one code fragment, two rows
-      }
-#pragma unroll
-      for (int j = 0; j < RB; ++j)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float gm = vmax(vmax(acc[j][4 * g], acc[j][4 * g + 1]), vmax(acc[j][4 * g + 2], acc[j][4 * g + 3]));
-          const bool gt = gm > best[j];   // strict: the first maximum wins, groups ascend per lane
-          best[j] = vmax(best[j], gm);
-          bsub[j] = gt ? 4 * u + g : bsub[j];
-        }
-    };
-    float before[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) before[j] = best[j];
-    if (nsub == CODES_LDS / 32) {
-      // full tile, unrolled with two accumulator sets: the C-operand loads of sub-tile u+1 are
-      // issued before the MFMAs of sub-tile u, so their LDS latency is never exposed
-      f32x16 cur = load_init(0);
-      AHead hcur = load_head(0);
-#pragma unroll
-      for (int u = 0; u < CODES_LDS / 32; ++u) {
-        f32x16 nxt = cur;
-        AHead hnxt = hcur;
-        if (u + 1 < CODES_LDS / 32) { nxt = load_init(u + 1); hnxt = load_head(u + 1); }
-        __builtin_amdgcn_sched_barrier(0);
-        subtile(u, cur, hcur);
-        cur = nxt;
-        hcur = hnxt;
-      }
-    } else {
-      for (int u = 0; u < nsub; ++u) subtile(u, load_init(u), load_head(u));
-    }
-#pragma unroll
-    for (int j = 0; j < RB; ++j) bbase[j] = (best[j] != before[j]) ? c0 : bbase[j];  // the tile base moves once per LDS tile
-  }
-  // first code of the winning group: tile base + 32 * sub-tile + 8 * group + 4 * half; merge the two half-waves of a row
-#pragma unroll
-  for (int j = 0; j < RB; ++j) {
-    const int64_t row = row0 + 32 * j;
-    int bidx = bbase[j] + 8 * bsub[j] + 4 * hf;
-    float b = best[j];
-    const float ob = __shfl_xor(b, 32, 64);
-    const int oi = __shfl_xor(bidx, 32, 64);
-    if (ob > b || (ob == b && oi < bidx)) { b = ob; bidx = oi; }
-    if (row < N && hf == 0) {
-      pmin[row * nsplit + split] = b;
-      pidx[row * nsplit + split] = bidx;
-    }
-  }
-}
-
 // ---------------------------------------------------------------------------------------
 template <int C>
 __global__ __launch_bounds__(FIN_ROWS * C / 4) void vq_finalize_kernel(
@@ -624,19 +436,9 @@ int launch_fwd(const float* z, const float* E, int64_t N, int K, int Kpad, int n
                int32_t* pidx, int64_t* idx, float* out, float* zq, float* zn, float* sqerr, hipStream_t st) {
   constexpr int LPR = C / 4;
   hipLaunchKernelGGL(vq_prep_codebook_kernel<C>, dim3((Kpad + 256 / LPR - 1) / (256 / LPR)), dim3(256), 0, st, E, K, Kpad, en, ee);
-  static const bool rows2 = [] { const char* e = getenv("AMK_VQ_ROWS2"); return !(e && e[0] == '0'); }();
-  if constexpr (C <= 64) {
-   if (rows2) {
-    const int64_t nrb2 = (N + 2 * ROWS_WG - 1) / (2 * ROWS_WG);
-    hipLaunchKernelGGL(vq_argmin2_kernel<C>, dim3((unsigned)(nrb2 * nsplit)), dim3(256), 0, st, z, en, ee, N, Kpad, nsplit, zn,
-                       pmin, pidx);
-   }
-  }
-  if (!(rows2 && C <= 64)) {
-    const int64_t nrb = (N + ROWS_WG - 1) / ROWS_WG;
-    hipLaunchKernelGGL(vq_argmin_kernel<C>, dim3((unsigned)(nrb * nsplit)), dim3(256), 0, st, z, en, ee, N, Kpad, nsplit, zn,
-                       pmin, pidx);
-  }
+  const int64_t nrb = (N + ROWS_WG - 1) / ROWS_WG;
+  hipLaunchKernelGGL(vq_argmin_kernel<C>, dim3((unsigned)(nrb * nsplit)), dim3(256), 0, st, z, en, ee, N, Kpad, nsplit, zn,
+                     pmin, pidx);
   hipLaunchKernelGGL(vq_finalize_kernel<C>, dim3((unsigned)((N + FIN_ROWS - 1) / FIN_ROWS)), dim3(FIN_ROWS * LPR), 0, st,
                      E, en, ee, zn, pmin, pidx, N, nsplit, idx, out, zq, sqerr);
   return 0;
