@@ -88,6 +88,11 @@ def kernel_rooflines(B, dev, iters):
     """Time each hand-written kernel at this workload's layer shape; return per-kernel dicts."""
     from amk import ops
 
+    # a full untimed pass in front of every timed one: the first launches of a kernel after other work run at another
+    # clock and with cold caches (tools/kbench_steady.py: round 0 against rounds 1+); what is reported is the steady state
+    def time_steady(fn, n):
+        return time_launches(fn, n, warm=max(3, n))
+
     H, T, D = VIT["n_heads"], (VIT["img_size"] // VIT["patch_size"]) ** 2, VIT["d_head"]
     g = torch.Generator().manual_seed(99)
     mk = lambda: torch.randn(B, T, H, D, generator=g).to(dev).permute(0, 2, 1, 3)  # (B,T,h*d) storage
@@ -104,42 +109,42 @@ def kernel_rooflines(B, dev, iters):
     core = 4.0 * B * H * T * T * D  # algorithmic FLOP of the forward
     layers_f, layers_b = 4 * VIT["depth"], 2 * VIT["depth"]  # per step: 2 model fwd + 1 bwd, enc+dec
     out = []
-    t = time_launches(lambda: ops._attn_forward(q, k, v, None, None, scale), iters)
+    t = time_steady(lambda: ops._attn_forward(q, k, v, None, None, scale), iters)
     out.append(dict(kernel="attn_fwd_kernel", launches_per_step=layers_f - layers_b, avg_ms=t * 1e3, flop=core,
                     note="4*B*h*I*J*d"))
     if scores is not None:
-        t = time_launches(lambda: ops._attn_forward(q, k, v, None, None, scale, keep_scores=True), iters)
+        t = time_steady(lambda: ops._attn_forward(q, k, v, None, None, scale, keep_scores=True), iters)
         out.append(dict(kernel="attn_fwd_keep_kernel", launches_per_step=layers_b, avg_ms=t * 1e3, flop=core,
                         note="4*B*h*I*J*d; also writes the raw scores (4*B*h*I*J bytes) for the backward"))
     old_mode, ops.ATTENTION_FORWARD = ops.ATTENTION_FORWARD, "bf16x6"
-    t = time_launches(lambda: ops._attn_forward(q, k, v, None, None, scale), iters)
+    t = time_steady(lambda: ops._attn_forward(q, k, v, None, None, scale), iters)
     ops.ATTENTION_FORWARD = old_mode
     out.append(dict(kernel="attn_fwd_x6 (split pre-pass + kernel)", launches_per_step=0, avg_ms=t * 1e3, flop=core,
                     note="the forward with split-bf16 products (amk_attn_fwd_x6); its bound is the bf16 MFMA peak / 6, "
                          "not the f32 MFMA peak the fraction below is taken against"))
     if scores is not None:
-        t = time_launches(lambda: bwd(main, scores), iters)
+        t = time_steady(lambda: bwd(main, scores), iters)
         out.append(dict(kernel="attn_bwd_fused_kernel(kept scores)", launches_per_step=layers_b, avg_ms=t * 1e3,
                         flop=2 * core, note="8*B*h*I*J*d (dV,dP,dQ,dK: the four products it runs; S is read back from "
                                             "the forward's score tiles); includes the dq memset"))
-        t = time_launches(lambda: bwd(72, scores), iters)
+        t = time_steady(lambda: bwd(72, scores), iters)
         out.append(dict(kernel="attn_bwd_fused_kernel(kept scores, reproducible dq)", launches_per_step=0, avg_ms=t * 1e3,
                         flop=2 * core, note="the same pass with dq as per-key-block partials + an ordered sum launch "
                                             "(no atomics, no memset; AMK_DETERMINISTIC=1)"))
-    t = time_launches(lambda: bwd(main), iters)
+    t = time_steady(lambda: bwd(main), iters)
     out.append(dict(kernel="attn_bwd_fused_kernel", launches_per_step=0 if scores is not None else layers_b,
                     avg_ms=t * 1e3, flop=2 * core,
                     note="8*B*h*I*J*d (dV,dP,dQ,dK; recomputed S not credited)"))
-    t = time_launches(lambda: bwd(2), iters)
+    t = time_steady(lambda: bwd(2), iters)
     out.append(dict(kernel="attn_bwd_dkdv_kernel", launches_per_step=0, avg_ms=t * 1e3, flop=core,
                     note="credited dV,dK products: 4*B*h*I*J*d (recomputed S, dP not credited)"))
-    t = time_launches(lambda: bwd(4), iters)
+    t = time_steady(lambda: bwd(4), iters)
     out.append(dict(kernel="attn_bwd_dq_kernel", launches_per_step=0, avg_ms=t * 1e3, flop=core,
                     note="credited dP,dQ products: 4*B*h*I*J*d (recomputed S not credited)"))
     N, K, C = B * T, CODEBOOK["codebook_size"], CODEBOOK["codebook_dim"]
     z = torch.randn(N, C, generator=g).to(dev)
     E = torch.randn(K, C, generator=g).to(dev)
-    t = time_launches(lambda: ops.vq_lookup(z, E, 0.25), iters)
+    t = time_steady(lambda: ops.vq_lookup(z, E, 0.25), iters)
     out.append(dict(kernel="vq_lookup_fwd (prep+argmin+finalize)", launches_per_step=2, avg_ms=t * 1e3,
                     flop=2.0 * N * K * C, note="2*N*K*C"))
     # head dims 32 and 128 (csrc/attn_generic.hip: plain forward, two recompute kernels backward) at the same token
@@ -152,17 +157,17 @@ def kernel_rooflines(B, dev, iters):
         qg, kg, vg, og, stg, scg = ops._attn_forward(qg, kg, vg, None, None, sg, keep_scores=True)   # (kept for head dim 128 only)
         dqg, dkg, dvg = (torch.empty_like(qg) for _ in range(3))
         coreg = 4.0 * B * Hg * T * T * Dg
-        t = time_launches(lambda: ops._attn_forward(qg, kg, vg, None, None, sg), iters)
+        t = time_steady(lambda: ops._attn_forward(qg, kg, vg, None, None, sg), iters)
         out.append(dict(kernel=f"attn_fwd_gen_kernel<{Dg}>", launches_per_step=0, avg_ms=t * 1e3, flop=coreg,
                         note=f"4*B*h*I*J*d at head dim {Dg}, {Hg} heads (unmasked: attn_fwd_gen_plain_kernel)"))
         if scg is not None:
-            t = time_launches(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=9, scores=scg), iters)
+            t = time_steady(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=9, scores=scg), iters)
             out.append(dict(kernel=f"attn_bwd_fused_gen_kernel<{Dg}>(kept scores) + delta", launches_per_step=0, avg_ms=t * 1e3,
                             flop=2 * coreg, note="8*B*h*I*J*d: the one-pass backward of csrc/attn_bwd_fused_gen.hip (four products)"))
-        t = time_launches(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=9), iters)
+        t = time_steady(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=9), iters)
         out.append(dict(kernel=f"attn_bwd_fused_gen_kernel<{Dg}> + delta", launches_per_step=0, avg_ms=t * 1e3,
                         flop=2 * coreg, note="8*B*h*I*J*d credited (five products: recomputed S not credited)"))
-        t = time_launches(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=7), iters)
+        t = time_steady(lambda: ops._attn_backward(qg, kg, vg, og, stg, dog, dqg, dkg, dvg, None, None, sg, stages=7), iters)
         out.append(dict(kernel=f"attn_bwd_gen_kernels<{Dg}> (delta + dkdv + dq)", launches_per_step=0, avg_ms=t * 1e3,
                         flop=2 * coreg, note="8*B*h*I*J*d credited (the reproducible recompute pair: seven products)"))
     for r in out:
