@@ -6,6 +6,8 @@ import sys
 from collections import defaultdict
 
 path, only = sys.argv[1], sys.argv[2:]
+RAW = "--raw" in only
+only = [o for o in only if o != "--raw"]
 acc = defaultdict(lambda: defaultdict(list))
 dur = defaultdict(list)
 seen = set()
@@ -39,4 +41,8 @@ for k, cs in acc.items():
     for n in ("FETCH_SIZE", "WRITE_SIZE"):
         if n in c:
             line += f"  {n} {c[n] / 1024:.1f} MiB"
+    if c.get("SQ_BUSY_CYCLES") and c.get("SQ_WAVE_CYCLES"):
+        line += f"  WAVE_CYCLES/BUSY_CYCLES {c['SQ_WAVE_CYCLES'] / c['SQ_BUSY_CYCLES']:.2f}"
+    if RAW:
+        line += "\n   " + "  ".join(f"{n}={v:.4g}" for n, v in sorted(c.items()))
     print(line)
