@@ -369,6 +369,33 @@ def dp_graph_ok(dev, world):
     return float(t.item()) >= 1.0, why
 
 
+def guarded_graph_attempt(attempt, fallback_line, rank):
+    """Run `attempt()` (pre-flight, capture and timing of the data-parallel step with its RCCL collectives inside a HIP graph)
+    under a deadline.  A captured collective that never completes cannot be caught as an exception: when the deadline passes,
+    rank 0 prints the already measured eager line and every rank leaves with os._exit(0) (each rank runs its own timer; a rank
+    is past the attempt only when the attempt's last collective -- the MAX over ranks of the timed steps -- has returned,
+    i.e. when every rank has finished it).  Returns attempt()'s result."""
+    import threading
+
+    deadline = float(os.environ.get("AMK_DP_GRAPH_DEADLINE", "150"))
+    done = threading.Event()
+
+    def watchdog():
+        if done.wait(deadline):
+            return
+        note(f"captured data-parallel step did not come back within {deadline:.0f} s: reporting the eager step")
+        if rank == 0:
+            fallback_line["graph_decision"] = f"captured-collectives attempt did not finish within {deadline:.0f} s; eager step reported"
+            emit(fallback_line)
+        os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+    try:
+        return attempt()
+    finally:
+        done.set()
+
+
 def capture_or_eager(capture, release, reducers, world, dev):
     """Capture the step; with several ranks every rank must have succeeded (MIN over ranks, an eager collective: the ones
     inside a capture were recorded, not run) -- otherwise every rank drops its graph and the step runs eagerly, with the
@@ -674,14 +701,24 @@ def main():
     # 92.7 ms of host work per step in round 2); N ranks: eager steps (the reducers' RCCL collectives run on a side stream)
     # N ranks over RCCL: the same single replay, with the reducers' all-reduces (side stream) captured inside it -- after
     # a pre-flight that captures and replays one small all-reduce on every rank (dp_graph_ok); over gloo (rehearsal): eager
-    use_graph, graph_why = (False, "--no-graph") if args.no_graph else dp_graph_ok(dev, world)
     communicating = world > 1 or alone_rccl
+    # Ranks that communicate over RCCL: the eager step (all-reduces on a side stream) is timed FIRST -- it is a valid headline on
+    # its own -- and the captured step (RCCL all-reduces inside the graph: never run on more than one GPU before the driver's
+    # scaling run) is attempted afterwards under a deadline: if the attempt does not come back, rank 0 prints the eager line
+    # and every rank leaves (guarded_graph_attempt).  One rank without communication: the graph directly, as before.
+    eager_first = communicating and not rehearse and not args.no_graph and os.environ.get("AMK_DP_GRAPH", "1") == "1"
+    if args.no_graph:
+        use_graph, graph_why = False, "--no-graph"
+    elif eager_first:
+        use_graph, graph_why = False, "eager first"
+    else:
+        use_graph, graph_why = dp_graph_ok(dev, world)
     overlap = {"on": True, "off": False, "auto": not (use_graph and communicating)}[args.dp_overlap]
     bf16 = args.autocast == "bf16"
     if bf16:
         args.no_kernels = args.no_variants = args.no_cpu_baseline = True
-    trainer = VQGANTrainStep(model, discr, capturable=use_graph, communicate_when_alone=alone_rccl, overlap=overlap,
-                             autocast=torch.bfloat16 if bf16 else None)
+    trainer = VQGANTrainStep(model, discr, capturable=use_graph or eager_first, communicate_when_alone=alone_rccl,
+                             overlap=True if eager_first else overlap, autocast=torch.bfloat16 if bf16 else None)
     g = torch.Generator().manual_seed(1234 + rank)
     imgs = torch.rand(args.batch, 3, VIT["img_size"], VIT["img_size"], generator=g).to(dev)
 
@@ -706,6 +743,46 @@ def main():
         sync()
         return time.perf_counter() - t0, logs
 
+    def max_over_ranks(x):
+        if world > 1:
+            tt = torch.tensor([x], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item())
+        return x
+
+    def headline(dt_, host_ms, graphed, why, ovl, loss_):
+        return {
+            "metric": "ViTVQGAN 256px train-step images/sec",
+            "value": args.batch * world * args.steps / dt_,
+            "unit": "images/s",
+            "n_gpus": world,
+            "n_ranks_seen": n_ranks_seen,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_ / args.steps * 1e3,
+            "host_enqueue_ms": host_ms,
+            "step_launch": ("one HIP-graph replay per step" + (" (RCCL all-reduces captured inside)" if communicating else ""))
+                           if graphed else "eager",
+            "graph_decision": why,
+            "dp_allreduce": ("side stream, overlapped with backward" if ovl else "compute stream, at bucket completion") if communicating else None,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16 (autocast)" if bf16 else "f32",
+            **({"secondary": True} if bf16 else {}),
+            "data": "synthetic U[0,1) images, random-init weights",
+            "config": {
+                "workload": "BASELINE.json configs[2]: ViTVQGAN dim=256 patch=8 img=256 depth=6+6 h=8 d=64 "
+                            "mlp=2048 (SwiGLU), codebook 8192x32; GAN train step (D phase + G phase, "
+                            "gradient penalty, per_loss_weight=0), Adam, clip 1.0",
+                "global_batch": args.batch * world,
+                "batch_per_gpu": args.batch,
+                "tokens_per_image": (VIT["img_size"] // VIT["patch_size"]) ** 2,
+                "parallelism": f"dp{world}",
+                "final_loss": loss_,
+            },
+        }
+
     note(f"rank {rank}/{world}: model built, batch {args.batch}/GPU")
     for _ in range(args.warmup):
         trainer.step(imgs)
@@ -717,11 +794,47 @@ def main():
     # ---- the headline: EXACTLY --steps steps, no instrumentation, barrier + synchronize on both sides
     dt, logs = timed_steps(args.steps)
     host_enqueue_ms = host_enqueue[0] * 1e3
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = max_over_ranks(dt)
     loss = float(logs["loss"])
+    dp_modes = None
+    if eager_first:
+        overlap = True
+        dp_modes = {"eager": {"ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms": host_enqueue_ms, "dp_allreduce": "side stream, overlapped with backward"}}
+        note(f"eager data-parallel step timed: {dt / args.steps * 1e3:.2f} ms; attempting the captured step under a deadline")
+        fallback = headline(dt, host_enqueue_ms, False, "placeholder", True, loss)
+
+        def attempt():
+            ok, why = dp_graph_ok(dev, world)
+            if os.environ.get("AMK_BENCH_FAKE_HANG") == "1":   # (test hook: the deadline path)
+                time.sleep(1e6)
+            if not ok:
+                return None, why
+            inline = {"on": False, "off": True, "auto": True}[args.dp_overlap]   # captured: all-reduces on the compute stream unless asked
+            for red in (trainer.g_red, trainer.d_red):
+                red.overlap = not inline
+            ok, why = capture_or_eager(lambda: trainer.capture(imgs), trainer.release_graph, [trainer.g_red, trainer.d_red], world, dev)
+            if not ok:
+                return None, why
+            dtg, lg = timed_steps(args.steps)
+            return (max_over_ranks(dtg), host_enqueue[0] * 1e3, float(lg["loss"]), not inline), why
+
+        res, why = guarded_graph_attempt(attempt, fallback, rank)
+        if res is not None:
+            dtg, hg, lossg, ovl_g = res
+            dp_modes["graph"] = {"ms_per_step": dtg / args.steps * 1e3, "host_enqueue_ms": hg,
+                                 "dp_allreduce": "side stream, overlapped with backward" if ovl_g else "compute stream, at bucket completion"}
+            # every rank takes the same branch: both times are MAX over ranks
+            if dtg <= dt:
+                dt, host_enqueue_ms, loss, use_graph, overlap = dtg, hg, lossg, True, ovl_g
+                graph_why = "captured step at least as fast as the eager one (both timed: dp_step_modes)"
+            else:
+                trainer.release_graph()
+                for red in (trainer.g_red, trainer.d_red):
+                    red.overlap = True
+                graph_why = "captured step slower than the eager one (both timed: dp_step_modes)"
+        else:
+            graph_why = why
+        note(f"data-parallel step: {graph_why}")
     note(f"timed {args.steps} steps in {dt:.3f}s")
 
     # ---- a separate short instrumented pass (rank 0): HIP events on the launch stream around every
@@ -857,38 +970,9 @@ def main():
         note("cpu baseline done")
 
     if rank == 0:
-        global_batch = args.batch * world
-        line = {
-            "metric": "ViTVQGAN 256px train-step images/sec",
-            "value": global_batch * args.steps / dt,
-            "unit": "images/s",
-            "n_gpus": world,
-            "n_ranks_seen": n_ranks_seen,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "host_enqueue_ms": host_enqueue_ms,
-            "step_launch": ("one HIP-graph replay per step" + (" (RCCL all-reduces captured inside)" if world > 1 or alone_rccl else ""))
-                           if use_graph else "eager",
-            "graph_decision": graph_why,
-            "dp_allreduce": ("side stream, overlapped with backward" if overlap else "compute stream, at bucket completion") if communicating else None,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16 (autocast)" if bf16 else "f32",
-            **({"secondary": True} if bf16 else {}),
-            "data": "synthetic U[0,1) images, random-init weights",
-            "config": {
-                "workload": "BASELINE.json configs[2]: ViTVQGAN dim=256 patch=8 img=256 depth=6+6 h=8 d=64 "
-                            "mlp=2048 (SwiGLU), codebook 8192x32; GAN train step (D phase + G phase, "
-                            "gradient penalty, per_loss_weight=0), Adam, clip 1.0",
-                "global_batch": global_batch,
-                "batch_per_gpu": args.batch,
-                "tokens_per_image": (VIT["img_size"] // VIT["patch_size"]) ** 2,
-                "parallelism": f"dp{world}",
-                "final_loss": loss,
-            },
-        }
+        line = headline(dt, host_enqueue_ms, use_graph, graph_why, overlap, loss)
+        if dp_modes:
+            line["dp_step_modes"] = dp_modes
         T_ = (VIT["img_size"] // VIT["patch_size"]) ** 2
         core = 4.0 * args.batch * VIT["n_heads"] * T_ * T_ * VIT["d_head"]
         flop_of = {"attn_fwd_kernel": core, "attn_fwd_keep_kernel": core, "attn_bwd_fused_kernel": 2 * core,

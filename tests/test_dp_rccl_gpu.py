@@ -207,3 +207,33 @@ def test_two_ranks_mixed_precision_direct_gradients(device, tmp_path):
     r1 = torch.load(tmp_path / "mixed_rank1.pt", weights_only=True)
     for a, b in zip(r0, r1):
         assert torch.equal(a, b)      # three optimizer steps later the replicas are still identical
+
+
+def _bench_line(extra_env, batch=2):
+    """bench.py as a child process (a world of one rank that communicates over RCCL anyway); returns (exit code, JSON line)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, AMK_BENCH_RCCL_ALONE="1", AMK_MIOPEN_FIND="0", AMK_TUNABLEOP="0", **extra_env)
+    for k in ("MASTER_ADDR", "MASTER_PORT", "RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", str(batch),
+                        "--no-cpu-baseline", "--no-kernels", "--no-variants"], env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    return r.returncode, json.loads(lines[0])
+
+
+def test_bench_times_the_eager_step_first_and_survives_a_hung_capture():
+    """Ranks that communicate: bench.py times the eager step, then attempts the captured one under a deadline.  With the
+    attempt stuck (test hook) the eager line must still come out, exit code 0; without the hook both modes are in the line."""
+    rc, line = _bench_line({"AMK_BENCH_FAKE_HANG": "1", "AMK_DP_GRAPH_DEADLINE": "15"})
+    assert rc == 0
+    assert line["step_launch"] == "eager" and "did not finish" in line["graph_decision"]
+    assert line["value"] > 0 and line["dp_allreduce"].startswith("side stream")
+    rc, line = _bench_line({})
+    assert rc == 0
+    assert set(line["dp_step_modes"]) == {"eager", "graph"}
+    assert line["value"] > 0
