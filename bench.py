@@ -331,7 +331,7 @@ def dp_graph_ok(dev, world):
     data-parallel step runs eagerly.  World of one: nothing to capture."""
     if world == 1 and not dist.is_initialized():
         return True, "one rank"
-    if os.environ.get("AMK_DP_GRAPH", "1") != "1":
+    if os.environ.get("AMK_DP_GRAPH", "auto") == "0":
         return False, "AMK_DP_GRAPH=0"
     if dist.get_backend() != "nccl":
         return False, f"backend {dist.get_backend()} cannot be captured"
@@ -706,7 +706,11 @@ def main():
     # its own -- and the captured step (RCCL all-reduces inside the graph: never run on more than one GPU before the driver's
     # scaling run) is attempted afterwards under a deadline: if the attempt does not come back, rank 0 prints the eager line
     # and every rank leaves (guarded_graph_attempt).  One rank without communication: the graph directly, as before.
-    eager_first = communicating and not rehearse and not args.no_graph and os.environ.get("AMK_DP_GRAPH", "1") == "1"
+    # AMK_DP_GRAPH: "auto" (default) attempts the captured step only where it can matter -- when the eager step is HOST-bound
+    # (host enqueue >= 0.6 of the step on some rank: the bf16 step); the f32 step is GPU-bound (46 of 108 ms) and a native
+    # crash inside a captured collective, unlike a hang, could not be turned into a line.  "1": always attempt; "0": never.
+    dp_graph_env = os.environ.get("AMK_DP_GRAPH", "auto")
+    eager_first = communicating and not rehearse and not args.no_graph and dp_graph_env in ("auto", "1")
     if args.no_graph:
         use_graph, graph_why = False, "--no-graph"
     elif eager_first:
@@ -802,6 +806,7 @@ def main():
         dp_modes = {"eager": {"ms_per_step": dt / args.steps * 1e3, "host_enqueue_ms": host_enqueue_ms, "dp_allreduce": "side stream, overlapped with backward"}}
         note(f"eager data-parallel step timed: {dt / args.steps * 1e3:.2f} ms; attempting the captured step under a deadline")
         fallback = headline(dt, host_enqueue_ms, False, "placeholder", True, loss)
+        host_bound = max_over_ranks(host_enqueue_ms / (dt / args.steps * 1e3)) >= 0.6
 
         def attempt():
             ok, why = dp_graph_ok(dev, world)
@@ -818,7 +823,12 @@ def main():
             dtg, lg = timed_steps(args.steps)
             return (max_over_ranks(dtg), host_enqueue[0] * 1e3, float(lg["loss"]), not inline), why
 
-        res, why = guarded_graph_attempt(attempt, fallback, rank)
+        if dp_graph_env == "auto" and not host_bound:
+            res, why = None, (f"eager: the step is GPU-bound (host enqueue {host_enqueue_ms:.0f} of {dt / args.steps * 1e3:.0f} ms per step), so the "
+                              "captured-collectives step was not attempted (AMK_DP_GRAPH=1 attempts it; measured with a world of one "
+                              "rank in dp_step_rccl_world_of_one of the one-GPU line)")
+        else:
+            res, why = guarded_graph_attempt(attempt, fallback, rank)
         if res is not None:
             dtg, hg, lossg, ovl_g = res
             dp_modes["graph"] = {"ms_per_step": dtg / args.steps * 1e3, "host_enqueue_ms": hg,

@@ -229,11 +229,11 @@ def _bench_line(extra_env, batch=2):
 def test_bench_times_the_eager_step_first_and_survives_a_hung_capture():
     """Ranks that communicate: bench.py times the eager step, then attempts the captured one under a deadline.  With the
     attempt stuck (test hook) the eager line must still come out, exit code 0; without the hook both modes are in the line."""
-    rc, line = _bench_line({"AMK_BENCH_FAKE_HANG": "1", "AMK_DP_GRAPH_DEADLINE": "15"})
+    rc, line = _bench_line({"AMK_BENCH_FAKE_HANG": "1", "AMK_DP_GRAPH_DEADLINE": "15", "AMK_DP_GRAPH": "1"})
     assert rc == 0
     assert line["step_launch"] == "eager" and "did not finish" in line["graph_decision"]
     assert line["value"] > 0 and line["dp_allreduce"].startswith("side stream")
-    rc, line = _bench_line({})
+    rc, line = _bench_line({"AMK_DP_GRAPH": "1"})
     assert rc == 0
     assert set(line["dp_step_modes"]) == {"eager", "graph"}
     assert line["value"] > 0
