@@ -183,39 +183,47 @@ __global__ __launch_bounds__(256, (C <= 64 ? 2 : 1)) void vq_argmin_kernel(const
       const float* er = &Es[(32 * u + ln) * LS + HC * hf];
       return AHead{ld4(er), ld4(er + 4)};
     };
-    auto subtile = [&](int u, f32x16 acc, const AHead& hd) {
+    auto chain = [&](int u, f32x16 acc, const AHead& hd, int s_lo, int s_hi) {   // k-steps [4 s_lo, 4 s_hi) of sub-tile u's MFMA chain
       const float* er = &Es[(32 * u + ln) * LS + HC * hf];
 #pragma unroll
-      for (int s4 = 0; s4 < HC / 4; ++s4) {
+      for (int s4 = s_lo; s4 < s_hi; ++s4) {
         const float4 a = s4 == 0 ? hd.a0 : (s4 == 1 ? hd.a1 : ld4(er + 4 * s4));
 #pragma unroll
         for (int e = 0; e < 4; ++e) acc = mfma32(f4(a, e), zreg[4 * s4 + e], acc);
       }
-      // acc[r] = dot - ee/2 for code (r&3) + 8*(r>>2) + 4*half of the sub-tile: registers 4g..4g+3
-      // are 4 consecutive codes.  Running max over groups; the index is (sub-tile base, group).
+      return acc;
+    };
+    // acc[r] = dot - ee/2 for code (r&3) + 8*(r>>2) + 4*half of the sub-tile: registers 4g..4g+3
+    // are 4 consecutive codes.  Running max over groups; the index is (sub-tile base, group).
+    auto argmax4 = [&](int u, const f32x16& acc) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const float gm = vmax(vmax(acc[4 * g], acc[4 * g + 1]), vmax(acc[4 * g + 2], acc[4 * g + 3]));
-        const bool gt = gm > best;   // strict: the first maximum wins, groups ascend per lane
-        best = vmax(best, gm);
-        bsub = gt ? 4 * u + g : bsub;  // an inline constant in the unrolled tile
+        // the running maximum folded into the group's max chain: nb = max(best, group) in two v_max3, and nb != best exactly
+        // when the group's maximum is strictly greater (the first maximum wins, groups ascend per lane): 4 instructions per
+        // group (round 4; 5 with a separate group maximum, compare and running max)
+        const float nb = vmax(vmax(vmax(vmax(acc[4 * g], acc[4 * g + 1]), acc[4 * g + 2]), acc[4 * g + 3]), best);
+        bsub = nb != best ? 4 * u + g : bsub;  // an inline constant in the unrolled tile
+        best = nb;
       }
     };
+    auto subtile = [&](int u, f32x16 acc, const AHead& hd) { argmax4(u, chain(u, acc, hd, 0, HC / 4)); };
     const float before = best;
     if (nsub == CODES_LDS / 32) {
-      // full tile, unrolled with two accumulator sets: the C-operand loads of sub-tile u+1 are
-      // issued before the MFMAs of sub-tile u, so their LDS latency is never exposed
-      f32x16 cur = load_init(0);
-      AHead hcur = load_head(0);
+      // full tile, sub-tiles software-pipelined: the argmax of sub-tile u stands BEHIND the first MFMAs of sub-tile u + 1 in
+      // program order, so the wave does not idle through the MFMA-result hazard (the s_nop 15 + s_nop 1 the compiler puts
+      // between a chain's last MFMA and the first v_max that reads it)
+      f32x16 done = chain(0, load_init(0), load_head(0), 0, HC / 4);
 #pragma unroll
       for (int u = 0; u < CODES_LDS / 32; ++u) {
-        f32x16 nxt = cur;
-        AHead hnxt = hcur;
-        if (u + 1 < CODES_LDS / 32) { nxt = load_init(u + 1); hnxt = load_head(u + 1); }
+        f32x16 nxt = done;
+        if (u + 1 < CODES_LDS / 32) {
+          nxt = chain(u + 1, load_init(u + 1), load_head(u + 1), 0, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        argmax4(u, done);
         __builtin_amdgcn_sched_barrier(0);
-        subtile(u, cur, hcur);
-        cur = nxt;
-        hcur = hnxt;
+        if (u + 1 < CODES_LDS / 32) nxt = chain(u + 1, nxt, load_head(u + 1), 1, HC / 4);
+        done = nxt;
       }
     } else {
       for (int u = 0; u < nsub; ++u) subtile(u, load_init(u), load_head(u));
