@@ -13,9 +13,11 @@
 //          at -ee/2 (read from LDS straight into the MFMA's C operand), so the score comes out of
 //          the matrix pipe with no VALU work.  Every VALU instruction is paid against the f32
 //          MFMA pipe (4 cycles each, measured: 1024 + 4*n cycles per tile), so the sweep only keeps
-//          a running max over GROUPS of 4 consecutive codes (max tree + cmp/max/select per group:
-//          22 instructions per tile instead of 86 for a per-code argmin) with strict '>' over
-//          ascending groups; the two half-waves of a row are merged at the end.
+//          a running max over GROUPS of 4 consecutive codes -- nb = max(best, the group's four) as two v_max3, then
+//          "nb != best" selects the group index: 16 instructions per 32-code tile (round 4; 22 with a separate group
+//          maximum, 86 for a per-code argmin); strict: the first maximum wins over ascending groups; the argmax of a
+//          sub-tile stands behind the first MFMAs of the next one, past the MFMA-result hazard; the two half-waves of a
+//          row are merged at the end.
 //   vq_finalize      : merges the per-slice (max, group) partials (lowest group wins ties), ranks
 //        the 4 codes of the winning group (strict '>' ascending = torch.argmin's first-minimum
 //        rule), gathers E[idx], re-normalises, forms the straight-through output and the
