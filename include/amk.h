@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define AMK_VERSION 135 /* 0.3.5: amk_agent_conv_grad_reduce; 0.3.4: amk_moe_route_distinct, _rows forms of combine / gate_grad; 0.3.3: amk_moe_expert_sums; 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
+#define AMK_VERSION 140 /* 0.4.0: amk_attn_bf16_fwd / _bwd take key_mask / causal_mask (signatures changed), the optimizer step takes a per-parameter table (decoupled weight decay, device-resident learning rate), one-pass backward for head dims 32 / 128 behind amk_attn_bwd; 0.3.5: amk_agent_conv_grad_reduce; 0.3.4: amk_moe_route_distinct, _rows forms of combine / gate_grad; 0.3.3: amk_moe_expert_sums; 0.3.2: bf16 forward / input-gradient GEMM; 0.3.1: bf16 weight-gradient GEMM; 0.3.0: dense f32 GEMMs with LayerNorm / SwiGLU / residual / bias-gradient fusions (amk_gemm_f32) */
 
 enum {
   AMK_OK = 0,

@@ -19,7 +19,7 @@ def test_library_exports_every_declared_symbol():
     L = amk_lib.load()
     for name in amk_lib.declared_symbols():
         assert hasattr(L, name), f"libamk.so does not export {name}"
-    assert L.amk_version() == 135
+    assert L.amk_version() == 140
     assert L.amk_arch() == b"gfx950"
 
 
